@@ -1,0 +1,125 @@
+/*
+ * pct_hip.h -- C ABI of the MI355X (gfx950) per-point curvature path.
+ *
+ * The reference has no FFI layer: its boundary is the Python class PointCloud
+ * (/root/reference/pointCloudToolbox.py:24).  These entry points are what the
+ * methods on that class's hot path bind to through ctypes; each one cites the
+ * reference method it replaces.  Plain C types only, caller-allocated output
+ * buffers, int status return (PCT_OK == 0), blocking semantics, one HIP stream
+ * per handle, no global mutable state (several handles / ranks may coexist).
+ */
+#ifndef PCT_HIP_H
+#define PCT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pct_ctx pct_ctx;
+
+enum pct_status {
+    PCT_OK = 0,
+    PCT_ERR_HIP = 1,          /* a HIP runtime call failed (see pct_last_error)        */
+    PCT_ERR_NO_DEVICE = 2,    /* no usable gfx950 device                               */
+    PCT_ERR_INVALID = 3,      /* bad argument / call order                             */
+    PCT_ERR_NONFINITE = 4,    /* NaN/Inf in the cloud (pointCloudToolbox.py:273-274)   */
+    PCT_ERR_K_TOO_LARGE = 5,  /* k + 1 > N (reference: IndexError at pct:640)          */
+    PCT_ERR_OOM = 6,
+    PCT_ERR_NO_NEIGHBORS = 7  /* fit requested before a neighbour table exists         */
+};
+
+enum pct_knn_algo {
+    PCT_KNN_AUTO = 0,
+    PCT_KNN_BRUTE = 1,        /* exhaustive wave-per-query sweep                        */
+    PCT_KNN_GRID = 2          /* uniform cell list, LDS-staged 27-cell stencil          */
+};
+
+/* Per-stage device times of the most recent call, hipEvent milliseconds. */
+typedef struct pct_timings {
+    float upload_ms;          /* H2D of coordinates (0 when device-resident)            */
+    float grid_ms;            /* bounding box + cell sizing + counting sort             */
+    float knn_ms;             /* neighbour sweep kernel(s) only                         */
+    float fit_ms;             /* fused plane-align + quadric fit + curvature kernel     */
+    float export_ms;          /* sorted-space -> public index translation               */
+    float total_ms;
+    int32_t knn_launches;
+    int32_t grid_iters;       /* cell-size refinement passes                            */
+    int64_t cells;            /* grid cells                                             */
+    int64_t occupied_cells;
+    int64_t ring_fallbacks;   /* queries that needed more than the 27-cell stencil      */
+    int64_t lds_overflows;    /* cells whose stencil exceeded the LDS staging capacity  */
+    double cell_size;
+} pct_timings;
+
+/* ---- lifetime ---------------------------------------------------------- */
+int pct_device_count(int* count);
+int pct_create(int device, pct_ctx** out);
+void pct_destroy(pct_ctx* ctx);
+const char* pct_last_error(const pct_ctx* ctx);    /* never NULL */
+const char* pct_version(void);
+
+/* ---- cloud upload: PointCloud.__init__ / read_from_file (pct:26-66) ----- */
+/* (n,3) row-major host coordinates.  The float32 form is the file path's
+ * dtype (pct:52); the float64 form keeps native-dtype queries and centring
+ * (pct:83, pct:641) while the search structure holds float32-rounded
+ * coordinates (pct:74). */
+int pct_set_points_f32(pct_ctx* ctx, const float* xyz, int64_t n);
+int pct_set_points_f64(pct_ctx* ctx, const double* xyz, int64_t n);
+/* Same, from a device pointer on this handle's device (multi-GPU: the buffer
+ * an RCCL all-gather has just filled). */
+int pct_set_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n);
+/* Queries owned by this handle: global index range [begin, end).  Default all. */
+int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end);
+/* Cell-occupancy target of the grid search as a multiple of (k+1); <= 0 keeps
+ * the default. */
+int pct_set_grid_param(pct_ctx* ctx, double occupancy_factor);
+
+/* ---- plant_kdtree(k) (pct:69-89) ---------------------------------------- */
+/* k nearest neighbours of every owned point, self dropped, rows ascending.
+ * eps > 0 adds the hybrid bound "distance < eps" (SURVEY A11); rows then carry
+ * a valid count, missing slots index N / distance +inf. */
+int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo);
+/* Lazy download of the neighbour table for rows [begin,end) of the cloud:
+ * idx (rows,k) int32, dist (rows,k) float32, count (rows) int32 (any may be NULL). */
+int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
+                      int32_t* idx, float* dist, int32_t* count);
+
+/* ---- fit_explicit_quadratic_surfaces_to_neighborhoods (pct:635-647)
+ *      + calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points
+ *        (pct:657-674) ---------------------------------------------------- */
+/* From the device-resident neighbour table left by pct_knn. */
+int pct_fit(pct_ctx* ctx);
+/* From host-supplied neighbours: idx (rows,k) int32 for query points
+ * query[rows] (NULL = 0..rows-1), optional per-row valid count. */
+int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count,
+                    const int64_t* query, int64_t rows, int32_t k);
+/* plant_kdtree + compute_pointwise_explicit_quadratic_curvature (pct:505-509)
+ * without materialising the neighbour table on the host. */
+int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo);
+
+/* Results of the last fit for cloud rows [begin,end) (pct_fit / pct_curvature)
+ * or for the rows of the last pct_fit_indices call.  Any pointer may be NULL.
+ * coefs (rows,6) float32 [A,B,C,D,E,F]; K, H, H2 (rows) float32. */
+int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end,
+                float* coefs, float* K, float* H, float* H2);
+
+/* calculate_explicit_quadratic_curvatures (pct:398-431) on caller-supplied
+ * coefficients: coefs (rows,6) float32 host -> K, H, H2 (rows) float32 host. */
+int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t rows,
+                                     float* K, float* H, float* H2);
+
+/* ---- measurement -------------------------------------------------------- */
+int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
+/* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */
+int pct_device_alloc(pct_ctx* ctx, int64_t bytes, void** dev_ptr);
+int pct_device_free(pct_ctx* ctx, void* dev_ptr);
+int pct_device_upload(pct_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes);
+int pct_device_download(pct_ctx* ctx, void* host_dst, const void* dev_src, int64_t bytes);
+int pct_synchronize(pct_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCT_HIP_H */

@@ -1,0 +1,248 @@
+"""ctypes binding of libpct_hip.so (C ABI: include/pct_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no gfx950
+device is usable every entry point raises.  Build with
+``python -c "import __graft_entry__ as g; g.build()"`` (drives hipcc).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpct_hip.so")
+
+PCT_OK = 0
+PCT_ERR_HIP = 1
+PCT_ERR_NO_DEVICE = 2
+PCT_ERR_INVALID = 3
+PCT_ERR_NONFINITE = 4
+PCT_ERR_K_TOO_LARGE = 5
+PCT_ERR_OOM = 6
+PCT_ERR_NO_NEIGHBORS = 7
+
+KNN_AUTO, KNN_BRUTE, KNN_GRID = 0, 1, 2
+
+
+class Timings(C.Structure):
+    _fields_ = [
+        ("upload_ms", C.c_float), ("grid_ms", C.c_float), ("knn_ms", C.c_float),
+        ("fit_ms", C.c_float), ("export_ms", C.c_float), ("total_ms", C.c_float),
+        ("knn_launches", C.c_int32), ("grid_iters", C.c_int32),
+        ("cells", C.c_int64), ("occupied_cells", C.c_int64),
+        ("ring_fallbacks", C.c_int64), ("lds_overflows", C.c_int64),
+        ("cell_size", C.c_double),
+    ]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+_p = C.c_void_p
+_i32p = C.POINTER(C.c_int32)
+_i64p = C.POINTER(C.c_int64)
+_f32p = C.POINTER(C.c_float)
+_f64p = C.POINTER(C.c_double)
+
+# name -> (restype, argtypes); every symbol declared in include/pct_hip.h
+SIGNATURES = {
+    "pct_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "pct_create": (C.c_int, [C.c_int, C.POINTER(_p)]),
+    "pct_destroy": (None, [_p]),
+    "pct_last_error": (C.c_char_p, [_p]),
+    "pct_version": (C.c_char_p, []),
+    "pct_set_points_f32": (C.c_int, [_p, _f32p, C.c_int64]),
+    "pct_set_points_f64": (C.c_int, [_p, _f64p, C.c_int64]),
+    "pct_set_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
+    "pct_set_query_range": (C.c_int, [_p, C.c_int64, C.c_int64]),
+    "pct_set_grid_param": (C.c_int, [_p, C.c_double]),
+    "pct_knn": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
+    "pct_get_neighbors": (C.c_int, [_p, C.c_int64, C.c_int64, _i32p, _f32p, _i32p]),
+    "pct_fit": (C.c_int, [_p]),
+    "pct_fit_indices": (C.c_int, [_p, _i32p, _i32p, _i64p, C.c_int64, C.c_int32]),
+    "pct_curvature": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
+    "pct_get_fit": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p, _f32p]),
+    "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
+    "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
+    "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
+    "pct_device_free": (C.c_int, [_p, _p]),
+    "pct_device_upload": (C.c_int, [_p, _p, _p, C.c_int64]),
+    "pct_device_download": (C.c_int, [_p, _p, _p, C.c_int64]),
+    "pct_synchronize": (C.c_int, [_p]),
+}
+
+_lib = None
+
+
+class HipExtensionError(RuntimeError):
+    """The HIP extension is missing or unusable -- there is no CPU fallback."""
+
+
+def load():
+    """Load libpct_hip.so and attach prototypes.  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipExtensionError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run __graft_entry__.build()); this package has no CPU fallback")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover - depends on the machine
+        raise HipExtensionError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the ABI and this table diverge
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def device_count():
+    n = C.c_int(0)
+    load().pct_device_count(C.byref(n))
+    return n.value
+
+
+def _ptr(a, typ):
+    return None if a is None else a.ctypes.data_as(typ)
+
+
+class Handle:
+    """One device context (one HIP stream) -- thin, typed wrapper over pct_ctx."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        self._h = _p()
+        st = self._lib.pct_create(int(device), C.byref(self._h))
+        if st != PCT_OK:
+            self._h = _p()
+            raise HipExtensionError(
+                f"pct_create(device={device}) failed with status {st}: no usable MI355X (gfx950) device; "
+                "this package has no CPU fallback")
+        self.device = int(device)
+
+    # -- plumbing ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.pct_destroy(self._h)
+            self._h = _p()
+
+    __del__ = close
+
+    def _check(self, st):
+        if st == PCT_OK:
+            return
+        msg = self._lib.pct_last_error(self._h).decode("utf-8", "replace")
+        if st == PCT_ERR_NONFINITE:
+            raise ValueError(msg or "Non-finite values in input points")     # pct:274
+        if st == PCT_ERR_K_TOO_LARGE:
+            raise IndexError(msg)                                            # reference: IndexError at pct:640
+        if st == PCT_ERR_INVALID:
+            raise ValueError(msg)
+        if st == PCT_ERR_OOM:
+            raise MemoryError(msg)
+        if st == PCT_ERR_NO_NEIGHBORS:
+            raise AttributeError(msg)                                        # reference: no self.neighbor_indices yet
+        raise HipExtensionError(f"status {st}: {msg}")
+
+    # -- cloud ------------------------------------------------------------
+    def set_points(self, pts):
+        pts = np.asarray(pts)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must have shape (N, 3)")
+        if pts.dtype == np.float64:
+            p = np.ascontiguousarray(pts)
+            self._check(self._lib.pct_set_points_f64(self._h, _ptr(p, _f64p), len(p)))
+        else:
+            p = np.ascontiguousarray(pts, dtype=np.float32)
+            self._check(self._lib.pct_set_points_f32(self._h, _ptr(p, _f32p), len(p)))
+        self.n = len(p)
+
+    def set_points_device(self, dev_ptr, n):
+        self._check(self._lib.pct_set_points_device_f32(self._h, _p(int(dev_ptr)), int(n)))
+        self.n = int(n)
+
+    def set_query_range(self, begin, end):
+        self._check(self._lib.pct_set_query_range(self._h, int(begin), int(end)))
+
+    def set_grid_param(self, occupancy_factor):
+        self._check(self._lib.pct_set_grid_param(self._h, float(occupancy_factor)))
+
+    # -- path -------------------------------------------------------------
+    def knn(self, k, eps=0.0, algo=KNN_AUTO):
+        self._check(self._lib.pct_knn(self._h, int(k), float(eps or 0.0), int(algo)))
+        self.k = int(k)
+
+    def fit(self):
+        self._check(self._lib.pct_fit(self._h))
+
+    def curvature(self, k, eps=0.0, algo=KNN_AUTO):
+        self._check(self._lib.pct_curvature(self._h, int(k), float(eps or 0.0), int(algo)))
+        self.k = int(k)
+
+    def get_neighbors(self, begin, end, want_idx=True, want_dist=True, want_count=False):
+        rows = int(end) - int(begin)
+        idx = np.empty((rows, self.k), np.int32) if want_idx else None
+        dist = np.empty((rows, self.k), np.float32) if want_dist else None
+        cnt = np.empty(rows, np.int32) if want_count else None
+        self._check(self._lib.pct_get_neighbors(self._h, int(begin), int(end), _ptr(idx, _i32p),
+                                                _ptr(dist, _f32p), _ptr(cnt, _i32p)))
+        return idx, dist, cnt
+
+    def fit_indices(self, idx, count=None, query=None):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.ndim != 2:
+            raise ValueError("neighbour indices must have shape (rows, k)")
+        cnt = None if count is None else np.ascontiguousarray(count, dtype=np.int32)
+        qry = None if query is None else np.ascontiguousarray(query, dtype=np.int64)
+        self._check(self._lib.pct_fit_indices(self._h, _ptr(idx, _i32p), _ptr(cnt, _i32p), _ptr(qry, _i64p),
+                                              idx.shape[0], idx.shape[1]))
+        return idx.shape[0]
+
+    def get_fit(self, begin, end, coefs=True, K=True, H=True, H2=True):
+        rows = int(end) - int(begin)
+        c = np.empty((rows, 6), np.float32) if coefs else None
+        k = np.empty(rows, np.float32) if K else None
+        h = np.empty(rows, np.float32) if H else None
+        h2 = np.empty(rows, np.float32) if H2 else None
+        self._check(self._lib.pct_get_fit(self._h, int(begin), int(end), _ptr(c, _f32p), _ptr(k, _f32p),
+                                          _ptr(h, _f32p), _ptr(h2, _f32p)))
+        return c, k, h, h2
+
+    def curvatures_from_coefficients(self, coefs):
+        c = np.ascontiguousarray(coefs, dtype=np.float32).reshape(-1, 6)
+        k = np.empty(len(c), np.float32)
+        h = np.empty(len(c), np.float32)
+        h2 = np.empty(len(c), np.float32)
+        self._check(self._lib.pct_curvatures_from_coefficients(self._h, _ptr(c, _f32p), len(c), _ptr(k, _f32p),
+                                                               _ptr(h, _f32p), _ptr(h2, _f32p)))
+        return k, h, h2
+
+    def timings(self):
+        t = Timings()
+        self._lib.pct_get_timings(self._h, C.byref(t))
+        return t.as_dict()
+
+    # -- raw device memory (multi-GPU all-gather target) ---------------------
+    def device_alloc(self, nbytes):
+        out = _p()
+        self._check(self._lib.pct_device_alloc(self._h, int(nbytes), C.byref(out)))
+        return out.value
+
+    def device_free(self, ptr):
+        self._check(self._lib.pct_device_free(self._h, _p(int(ptr))))
+
+    def device_upload(self, ptr, host):
+        host = np.ascontiguousarray(host)
+        self._check(self._lib.pct_device_upload(self._h, _p(int(ptr)), host.ctypes.data_as(_p), host.nbytes))
+
+    def device_download(self, ptr, host):
+        assert host.flags["C_CONTIGUOUS"]
+        self._check(self._lib.pct_device_download(self._h, host.ctypes.data_as(_p), _p(int(ptr)), host.nbytes))
+
+    def synchronize(self):
+        self._check(self._lib.pct_synchronize(self._h))

@@ -1,0 +1,393 @@
+// C ABI of the curvature path (include/pct_hip.h).  Host-side orchestration
+// only: buffer ownership, launch order, hipEvent timing, status mapping.
+#include "pct_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+
+int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...) {
+    if (ctx) {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+        va_end(ap);
+    }
+    return code;
+}
+
+int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b->cap >= bytes) return PCT_OK;
+    if (b->p) {
+        PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCT_HIP(ctx, hipFree(b->p));
+        b->p = nullptr;
+        b->cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;   // a little head-room for repeated calls with growing sizes
+    hipError_t e = hipMalloc(&b->p, want);
+    if (e != hipSuccess) {
+        b->p = nullptr;
+        return pct_fail(ctx, PCT_ERR_OOM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b->cap = want;
+    return PCT_OK;
+}
+
+static void release(pct_buf* b) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+}
+
+static float ev_ms(pct_ctx* ctx, int a, int b) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0.f;
+    return ms;
+}
+
+extern "C" {
+
+const char* pct_version(void) { return "pct_hip 0.1 (gfx950)"; }
+
+int pct_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) n = 0;
+    if (count) *count = n;
+    return e == hipSuccess ? PCT_OK : PCT_ERR_NO_DEVICE;
+}
+
+int pct_create(int device, pct_ctx** out) {
+    if (!out) return PCT_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PCT_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return PCT_ERR_NO_DEVICE;
+    pct_ctx* ctx = new pct_ctx();
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return PCT_ERR_HIP;
+    }
+    for (auto& e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete ctx;
+            return PCT_ERR_HIP;
+        }
+    *out = ctx;
+    return PCT_OK;
+}
+
+void pct_destroy(pct_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
+                      &ctx->scan_tmp, &ctx->occ, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
+                      &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
+                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
+    for (pct_buf* b : all) release(b);
+    for (auto& e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+const char* pct_last_error(const pct_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+static int begin_call(pct_ctx* ctx) {
+    if (!ctx) return PCT_ERR_INVALID;
+    ctx->err[0] = 0;
+    PCT_HIP(ctx, hipSetDevice(ctx->device));
+    return PCT_OK;
+}
+
+static int new_cloud(pct_ctx* ctx, int64_t n) {
+    if (n <= 0 || n > (int64_t)INT32_MAX - 1024) return pct_fail(ctx, PCT_ERR_INVALID, "cloud size %lld out of range", (long long)n);
+    ctx->n = n;
+    ctx->q_begin = 0;
+    ctx->q_end = n;
+    ctx->grid_valid = ctx->knn_valid = ctx->fit_valid = ctx->pts4_valid = false;
+    ctx->has_f64 = false;
+    ctx->tm = pct_timings{};
+    return PCT_OK;
+}
+
+int pct_set_points_f32(pct_ctx* ctx, const float* xyz, int64_t n) {
+    PCT_TRY(begin_call(ctx));
+    if (!xyz) return pct_fail(ctx, PCT_ERR_INVALID, "null coordinates");
+    PCT_TRY(new_cloud(ctx, n));
+    PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tm.upload_ms = ev_ms(ctx, 0, 1);
+    return PCT_OK;
+}
+
+int pct_set_points_f64(pct_ctx* ctx, const double* xyz, int64_t n) {
+    PCT_TRY(begin_call(ctx));
+    if (!xyz) return pct_fail(ctx, PCT_ERR_INVALID, "null coordinates");
+    PCT_TRY(new_cloud(ctx, n));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)n * 3 * sizeof(double)));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_pack_points_f64(ctx, (const double*)ctx->stage_a.p));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_f64 = true;
+    ctx->tm.upload_ms = ev_ms(ctx, 0, 1);
+    return PCT_OK;
+}
+
+int pct_set_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n) {
+    PCT_TRY(begin_call(ctx));
+    if (!dev_xyz) return pct_fail(ctx, PCT_ERR_INVALID, "null coordinates");
+    PCT_TRY(new_cloud(ctx, n));
+    PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->xyz.p, dev_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
+    if (begin < 0 || end > ctx->n || begin > end) return pct_fail(ctx, PCT_ERR_INVALID, "bad query range [%lld,%lld)", (long long)begin, (long long)end);
+    ctx->q_begin = begin;
+    ctx->q_end = end;
+    ctx->knn_valid = ctx->fit_valid = false;
+    return PCT_OK;
+}
+
+int pct_set_grid_param(pct_ctx* ctx, double occupancy_factor) {
+    PCT_TRY(begin_call(ctx));
+    ctx->occupancy_factor = occupancy_factor > 0 ? occupancy_factor : 0.0;
+    return PCT_OK;
+}
+
+// neighbour sweep without timing bookkeeping; events 2..4 bracket grid / sweep
+static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+    if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
+    if (k < 1 || k > 127) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,127]", k);
+    if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
+    if (!(eps >= 0) || isinf(eps)) eps = 0;
+    if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
+    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE) return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
+    ctx->knn_valid = ctx->fit_valid = false;
+    ctx->k = k;
+    ctx->eps = eps;
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    if (algo == PCT_KNN_GRID) {
+        PCT_TRY(pct_build_grid(ctx, k, eps));
+    } else {
+        float bbox[6];
+        PCT_TRY(pct_pack_points(ctx, bbox));
+        ctx->tm.grid_iters = 0;
+        ctx->tm.cells = ctx->tm.occupied_cells = 0;
+        ctx->tm.cell_size = 0;
+    }
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    if (algo == PCT_KNN_GRID)
+        PCT_TRY(pct_launch_knn_grid(ctx, k, eps));
+    else
+        PCT_TRY(pct_launch_knn_brute(ctx, k, eps));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+    ctx->tm.knn_launches = 1;
+    ctx->knn_valid = true;
+    return PCT_OK;
+}
+
+static int finish_knn_stats(pct_ctx* ctx) {
+    unsigned long long c[2] = {0, 0};
+    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tm.ring_fallbacks = (int64_t)c[0];
+    ctx->tm.lds_overflows = (int64_t)c[1];
+    ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
+    ctx->tm.knn_ms = ev_ms(ctx, 3, 4);
+    return PCT_OK;
+}
+
+int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+    PCT_TRY(begin_call(ctx));
+    PCT_TRY(run_knn(ctx, k, eps, algo));
+    PCT_TRY(finish_knn_stats(ctx));
+    ctx->tm.fit_ms = 0;
+    ctx->tm.total_ms = ev_ms(ctx, 2, 4);
+    return PCT_OK;
+}
+
+int pct_fit(pct_ctx* ctx) {
+    PCT_TRY(begin_call(ctx));
+    if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "plant the neighbour table first (pct_knn)");
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    PCT_TRY(pct_launch_fit_table(ctx));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
+    ctx->fit_rows = ctx->q_end - ctx->q_begin;
+    ctx->fit_valid = true;
+    return PCT_OK;
+}
+
+int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+    PCT_TRY(begin_call(ctx));
+    PCT_TRY(run_knn(ctx, k, eps, algo));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    PCT_TRY(pct_launch_fit_table(ctx));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    PCT_TRY(finish_knn_stats(ctx));
+    ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
+    ctx->tm.total_ms = ev_ms(ctx, 2, 6);
+    ctx->fit_rows = ctx->q_end - ctx->q_begin;
+    ctx->fit_valid = true;
+    return PCT_OK;
+}
+
+int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_t* idx, float* dist, int32_t* count) {
+    PCT_TRY(begin_call(ctx));
+    if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "no neighbour table");
+    if (begin < ctx->q_begin || end > ctx->q_end || begin > end)
+        return pct_fail(ctx, PCT_ERR_INVALID, "rows [%lld,%lld) outside the owned range [%lld,%lld)", (long long)begin,
+                        (long long)end, (long long)ctx->q_begin, (long long)ctx->q_end);
+    const int64_t rows = end - begin;
+    if (rows == 0) return PCT_OK;
+    const size_t cells = (size_t)rows * ctx->k;
+    if (idx) PCT_TRY(pct_reserve(ctx, &ctx->stage_a, cells * sizeof(int)));
+    if (dist) PCT_TRY(pct_reserve(ctx, &ctx->stage_b, cells * sizeof(float)));
+    if (count) PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)rows * sizeof(int)));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+    PCT_TRY(pct_launch_export_neighbors(ctx, begin, end, idx ? (int*)ctx->stage_a.p : nullptr,
+                                        dist ? (float*)ctx->stage_b.p : nullptr, count ? (int*)ctx->stage_c.p : nullptr));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+    if (idx) PCT_HIP(ctx, hipMemcpyAsync(idx, ctx->stage_a.p, cells * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) PCT_HIP(ctx, hipMemcpyAsync(dist, ctx->stage_b.p, cells * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (count) PCT_HIP(ctx, hipMemcpyAsync(count, ctx->stage_c.p, (size_t)rows * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tm.export_ms = ev_ms(ctx, 0, 1);
+    return PCT_OK;
+}
+
+int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
+    if (!idx || rows <= 0 || k < 1 || k > 4096) return pct_fail(ctx, PCT_ERR_INVALID, "bad neighbour rows");
+    // host-side validation: a bad index would fault the device
+    for (int64_t r = 0; r < rows; ++r) {
+        const int m = count ? count[r] : k;
+        if (m < 0 || m > k) return pct_fail(ctx, PCT_ERR_INVALID, "row %lld: count %d outside [0,%d]", (long long)r, m, k);
+        if (query && (query[r] < 0 || query[r] >= ctx->n)) return pct_fail(ctx, PCT_ERR_INVALID, "row %lld: query index out of range", (long long)r);
+        if (!query && r >= ctx->n) return pct_fail(ctx, PCT_ERR_INVALID, "more rows than points and no query list");
+        const int32_t* p = idx + r * k;
+        for (int j = 0; j < m; ++j)
+            if (p[j] < 0 || p[j] >= ctx->n)
+                return pct_fail(ctx, PCT_ERR_INVALID, "row %lld: neighbour index %d out of range (IndexError in the reference)", (long long)r, p[j]);
+    }
+    if (!ctx->pts4_valid) {
+        float bbox[6];
+        PCT_TRY(pct_pack_points(ctx, bbox));
+    }
+    const size_t cells = (size_t)rows * k;
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, cells * sizeof(int)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, idx, cells * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    if (count) {
+        PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)rows * sizeof(int)));
+        PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_c.p, count, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (query) {
+        PCT_TRY(pct_reserve(ctx, &ctx->stage_d, (size_t)rows * sizeof(int64_t)));
+        PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_d.p, query, (size_t)rows * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    }
+    PCT_TRY(pct_reserve(ctx, &ctx->coefs, (size_t)rows * 6 * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)rows * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->H, (size_t)rows * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->H2, (size_t)rows * sizeof(float)));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+    PCT_TRY(pct_launch_fit_rows(ctx, (const int*)ctx->stage_a.p, count ? (const int*)ctx->stage_c.p : nullptr,
+                                query ? (const int64_t*)ctx->stage_d.p : nullptr, rows, k, (float*)ctx->coefs.p,
+                                (float*)ctx->K.p, (float*)ctx->H.p, (float*)ctx->H2.p));
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
+    ctx->fit_rows = rows;
+    ctx->fit_valid = true;
+    ctx->knn_valid = false;   // results are row-aligned now, not cloud-aligned
+    return PCT_OK;
+}
+
+int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end, float* coefs, float* K, float* H, float* H2) {
+    PCT_TRY(begin_call(ctx));
+    if (!ctx->fit_valid) return pct_fail(ctx, PCT_ERR_INVALID, "no fit results");
+    const int64_t base = ctx->knn_valid ? ctx->q_begin : 0;   // cloud-aligned vs row-aligned results
+    if (begin < base || end > base + ctx->fit_rows || begin > end)
+        return pct_fail(ctx, PCT_ERR_INVALID, "rows [%lld,%lld) outside the fitted range", (long long)begin, (long long)end);
+    const int64_t rows = end - begin, off = begin - base;
+    if (rows == 0) return PCT_OK;
+    if (coefs) PCT_HIP(ctx, hipMemcpyAsync(coefs, (float*)ctx->coefs.p + off * 6, (size_t)rows * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (K) PCT_HIP(ctx, hipMemcpyAsync(K, (float*)ctx->K.p + off, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (H) PCT_HIP(ctx, hipMemcpyAsync(H, (float*)ctx->H.p + off, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (H2) PCT_HIP(ctx, hipMemcpyAsync(H2, (float*)ctx->H2.p + off, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t rows, float* K, float* H, float* H2) {
+    PCT_TRY(begin_call(ctx));
+    if (!coefs || rows <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "bad coefficient rows");
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)rows * 6 * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)rows * 3 * sizeof(float)));
+    float* d_out = (float*)ctx->stage_b.p;
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, coefs, (size_t)rows * 6 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_launch_curvatures(ctx, (const float*)ctx->stage_a.p, rows, d_out, d_out + rows, d_out + 2 * rows));
+    if (K) PCT_HIP(ctx, hipMemcpyAsync(K, d_out, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (H) PCT_HIP(ctx, hipMemcpyAsync(H, d_out + rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (H2) PCT_HIP(ctx, hipMemcpyAsync(H2, d_out + 2 * rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_get_timings(const pct_ctx* ctx, pct_timings* out) {
+    if (!ctx || !out) return PCT_ERR_INVALID;
+    *out = ctx->tm;
+    return PCT_OK;
+}
+
+int pct_device_alloc(pct_ctx* ctx, int64_t bytes, void** dev_ptr) {
+    PCT_TRY(begin_call(ctx));
+    if (!dev_ptr || bytes <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "bad allocation request");
+    hipError_t e = hipMalloc(dev_ptr, (size_t)bytes);
+    if (e != hipSuccess) return pct_fail(ctx, PCT_ERR_OOM, "hipMalloc(%lld) failed: %s", (long long)bytes, hipGetErrorString(e));
+    return PCT_OK;
+}
+
+int pct_device_free(pct_ctx* ctx, void* dev_ptr) {
+    PCT_TRY(begin_call(ctx));
+    if (dev_ptr) PCT_HIP(ctx, hipFree(dev_ptr));
+    return PCT_OK;
+}
+
+int pct_device_upload(pct_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes) {
+    PCT_TRY(begin_call(ctx));
+    PCT_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, (size_t)bytes, hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_device_download(pct_ctx* ctx, void* host_dst, const void* dev_src, int64_t bytes) {
+    PCT_TRY(begin_call(ctx));
+    PCT_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, (size_t)bytes, hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_synchronize(pct_ctx* ctx) {
+    PCT_TRY(begin_call(ctx));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// Fused per-point kernel for the three per-neighbourhood staticmethods of the
+// reference and the two all-points loops around them:
+//   get_best_fit_plane_and_rotate            pointCloudToolbox.py:270-321
+//   fit_quadratic_surface                    pointCloudToolbox.py:331-360
+//   calculate_explicit_quadratic_curvatures  pointCloudToolbox.py:398-431
+//   loops                                    pointCloudToolbox.py:635-647, 657-674
+//
+// One thread per point (tiny dense per-point algebra, no MFMA).  A 64-thread
+// workgroup stages its 64 neighbour-index rows into LDS with coalesced loads
+// (odd row pitch -> conflict-free column reads), then every lane walks its own
+// row twice:
+//   pass 1  centred neighbours (native dtype, pct:641) -> fp64 sums -> 3x3
+//           covariance about the neighbour mean, ddof=1 (pct:277) -> cyclic
+//           Jacobi eigen-solve -> normal = eigenvector of the smallest
+//           eigenvalue (== Vt[-1], pct:283) -> sign flip by far-minus-near
+//           neighbour (pct:286-297) -> Rodrigues rotation to +z (pct:300-312)
+//   pass 2  rotate (pct:315), round to float32 (pct:350), float32 design row
+//           [a^2,b^2,ab,a,b,1] (pct:358), fp64 normal equations with columns
+//           scaled by a power of two of the neighbourhood radius (exact),
+//           Cholesky solve, coefficients rounded to float32 (pct:359)
+//   then    K, H, H^2 in float32 arithmetic in the reference's operation order
+//           (pct:403-422).
+// Compiled with -ffp-contract=off so the float32 sequences are not fused.
+#include "pct_internal.h"
+
+#include <math.h>
+
+namespace {
+
+constexpr int kFitBlock = 64;
+
+struct FitArgs {
+    const float4* pts;       // records {x,y,z,public index}
+    const double4* ptsd;     // native fp64 coordinates (nullable), same order
+    const int* table;        // (rows,k) neighbour ids into pts (-1 = missing)
+    const int* cnt;          // (rows) valid neighbours per row (nullable -> k)
+    const int64_t* row_query;// (rows) query id into pts per row (nullable -> row)
+    int64_t rows;
+    int k;
+    int kp;                  // LDS row pitch (odd)
+    int out_by_row;          // 1: outputs indexed by row; 0: by public index of the query
+    int64_t out_base;        // subtracted from the public index when out_by_row == 0
+    int q_begin, q_end;      // owned public range (rows outside are skipped)
+    float* coefs;
+    float* K;
+    float* H;
+    float* H2;
+};
+
+#define JACOBI_ROT(app, aqq, apq, arp, arq, vp0, vp1, vp2, vq0, vq1, vq2)          \
+    do {                                                                            \
+        if (apq != 0.0) {                                                           \
+            const double theta = (aqq - app) / (2.0 * apq);                         \
+            const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
+            const double c = 1.0 / sqrt(t * t + 1.0);                               \
+            const double s = t * c;                                                 \
+            app -= t * apq;                                                         \
+            aqq += t * apq;                                                         \
+            apq = 0.0;                                                              \
+            const double rp = arp, rq = arq;                                        \
+            arp = c * rp - s * rq;                                                  \
+            arq = s * rp + c * rq;                                                  \
+            double a0 = vp0, b0 = vq0; vp0 = c * a0 - s * b0; vq0 = s * a0 + c * b0; \
+            double a1 = vp1, b1 = vq1; vp1 = c * a1 - s * b1; vq1 = s * a1 + c * b1; \
+            double a2 = vp2, b2 = vq2; vp2 = c * a2 - s * b2; vq2 = s * a2 + c * b2; \
+        }                                                                           \
+    } while (0)
+
+// K and H of z = A a^2 + B b^2 + C ab + D a + E b + F at the origin, float32
+// arithmetic in the reference's operation order (pct:403-419).
+__device__ __forceinline__ void monge_curvatures(float A, float B, float C, float D, float E, float& Kg, float& Kh) {
+    const float Fx = D, Fy = E;
+    const float Fxx = 2.0f * A, Fyy = 2.0f * B, Fxy = C;
+    const float fx2 = Fx * Fx, fy2 = Fy * Fy;
+    const float wgt = (1.0f + fx2) + fy2;
+    const float den_k = wgt * wgt;                                            // (...) ** 2
+    const float den_h = (float)((double)wgt * sqrt((double)wgt));            // (...) ** 1.5
+    Kg = (Fxx * Fyy - Fxy * Fxy) / den_k;
+    Kh = (((1.0f + fx2) * Fyy - ((2.0f * Fx) * Fy) * Fxy) + (1.0f + fy2) * Fxx) / (2.0f * den_h);
+}
+
+template <bool F64>
+__device__ __forceinline__ void load_centred(const FitArgs& a, int id, double qx, double qy, double qz,
+                                             float qxf, float qyf, float qzf, double& x, double& y, double& z) {
+    if (F64) {
+        const double4 p = a.ptsd[id];
+        x = p.x - qx; y = p.y - qy; z = p.z - qz;         // float64 cloud: float64 centring
+    } else {
+        const float4 p = a.pts[id];
+        x = (double)(p.x - qxf);                           // float32 cloud: float32 centring (pct:641)
+        y = (double)(p.y - qyf);
+        z = (double)(p.z - qzf);
+    }
+}
+
+template <bool F64>
+__global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
+    extern __shared__ int s_idx[];   // 64 rows x kp
+    const int lane = threadIdx.x;
+    const int64_t row0 = (int64_t)blockIdx.x * kFitBlock;
+    const int k = a.k, kp = a.kp;
+
+    // ---- stage 64 index rows, coalesced ---------------------------------
+    const int nrow = (int)min((int64_t)kFitBlock, a.rows - row0);
+    for (int r = 0; r < nrow; ++r) {
+        const int* src = a.table + (row0 + r) * k;
+        for (int j = lane; j < k; j += kFitBlock) s_idx[r * kp + j] = src[j];
+    }
+    __syncthreads();
+
+    const int64_t row = row0 + lane;
+    if (row >= a.rows) return;
+    const int64_t qid = a.row_query ? a.row_query[row] : row;
+    const float4 qp = a.pts[qid];
+    const int pub = __float_as_int(qp.w);
+    if (!a.out_by_row && (pub < a.q_begin || pub >= a.q_end)) return;
+    const int64_t out = a.out_by_row ? row : (int64_t)pub - a.out_base;
+
+    double qx = qp.x, qy = qp.y, qz = qp.z;
+    if (F64) {
+        const double4 qd = a.ptsd[qid];
+        qx = qd.x; qy = qd.y; qz = qd.z;
+    }
+    const int m = a.cnt ? a.cnt[row] : k;
+    const int* my = s_idx + lane * kp;
+    const float nanf_ = __int_as_float(0x7fc00000);
+
+    if (m < 6) {   // under-determined quadric (only reachable through the eps bound)
+        for (int j = 0; j < 6; ++j) a.coefs[out * 6 + j] = nanf_;
+        a.K[out] = nanf_; a.H[out] = nanf_; a.H2[out] = nanf_;
+        return;
+    }
+
+    // ---- pass 1: moments of the centred neighbourhood ---------------------
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0, r2max = 0;
+    double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
+    for (int j = 0; j < m; ++j) {
+        double x, y, z;
+        load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+        if (j == 0) { fx = x; fy = y; fz = z; }
+        lx = x; ly = y; lz = z;
+        sx += x; sy += y; sz += z;
+        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
+        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
+        r2max = fmax(r2max, (x * x + y * y) + z * z);
+    }
+    const double inv_m = 1.0 / (double)m, inv_m1 = 1.0 / (double)(m - 1);
+    const double mx = sx * inv_m, my_ = sy * inv_m, mz = sz * inv_m;
+    double a00 = (sxx - sx * mx) * inv_m1, a01 = (sxy - sx * my_) * inv_m1, a02 = (sxz - sx * mz) * inv_m1;
+    double a11 = (syy - sy * my_) * inv_m1, a12 = (syz - sy * mz) * inv_m1, a22 = (szz - sz * mz) * inv_m1;
+
+    // ---- cyclic Jacobi on the symmetric 3x3 --------------------------------
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // v[row][col]
+#pragma unroll 1
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        const double off = fabs(a01) + fabs(a02) + fabs(a12);
+        if (off == 0.0) break;
+        JACOBI_ROT(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21);   // (p,q)=(0,1), r=2
+        JACOBI_ROT(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);   // (0,2), r=1
+        JACOBI_ROT(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);   // (1,2), r=0
+    }
+    double n0, n1, n2;
+    if (a00 <= a11 && a00 <= a22) { n0 = v00; n1 = v10; n2 = v20; }
+    else if (a11 <= a22)          { n0 = v01; n1 = v11; n2 = v21; }
+    else                          { n0 = v02; n1 = v12; n2 = v22; }
+
+    // ---- orientation: far-minus-near neighbour (pct:286-297) ---------------
+    double rx, ry, rz;
+    if (F64) { rx = lx - fx; ry = ly - fy; rz = lz - fz; }
+    else     { rx = (double)((float)lx - (float)fx); ry = (double)((float)ly - (float)fy); rz = (double)((float)lz - (float)fz); }
+    {
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        const double rn = sqrt((rx * rx + ry * ry) + rz * rz);
+        const double dot = ((n0 / nn) * (rx / rn) + (n1 / nn) * (ry / rn)) + (n2 / nn) * (rz / rn);
+        if (dot < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+    }
+    // ---- Rodrigues rotation taking the normal to +z (pct:300-312) -----------
+    double r00 = 1, r01 = 0, r02 = 0, r10 = 0, r11 = 1, r12 = 0, r20 = 0, r21 = 0, r22 = 1;
+    {
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        const double ax = n0 / nn, ay = n1 / nn, az = n2 / nn;
+        const double v0 = ay, v1 = -ax;                    // a x (0,0,1)
+        const double c = az;
+        const double s = sqrt(v0 * v0 + v1 * v1);
+        if (s != 0.0) {
+            const double f = (1.0 - c) / (s * s);
+            r00 = 1.0 + (-(v1 * v1)) * f;  r01 = (v1 * v0) * f;            r02 = v1;
+            r10 = (v0 * v1) * f;           r11 = 1.0 + (-(v0 * v0)) * f;   r12 = -v0;
+            r20 = -v1;                     r21 = v0;                       r22 = 1.0 + (-(v1 * v1) + -(v0 * v0)) * f;
+        }
+    }
+
+    // ---- pass 2: float32 design rows -> scaled fp64 normal equations --------
+    int e2 = 0;
+    if (r2max > 0) { int ex; frexp(sqrt(r2max), &ex); e2 = -ex; }   // radius * 2^e2 in [0.5, 1)
+    const double s1 = ldexp(1.0, e2), s2 = ldexp(1.0, 2 * e2);
+    double g[21];
+    double b[6];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) g[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) b[i] = 0;
+    for (int j = 0; j < m; ++j) {
+        double x, y, z;
+        load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+        const float pa = (float)((r00 * x + r01 * y) + r02 * z);
+        const float pb = (float)((r10 * x + r11 * y) + r12 * z);
+        const float pz = (float)((r20 * x + r21 * y) + r22 * z);
+        double c[6];
+        c[0] = (double)(pa * pa) * s2;
+        c[1] = (double)(pb * pb) * s2;
+        c[2] = (double)(pa * pb) * s2;
+        c[3] = (double)pa * s1;
+        c[4] = (double)pb * s1;
+        c[5] = 1.0;
+        const double zz = (double)pz;
+        int t = 0;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int jj = 0; jj <= i; ++jj) { g[t] = fma(c[i], c[jj], g[t]); ++t; }
+            b[i] = fma(c[i], zz, b[i]);
+        }
+    }
+
+    // ---- Cholesky  G = L L^T  (lower triangle packed row-wise), solve -------
+    // packed index of (i,j), j<=i : i*(i+1)/2 + j
+#define GI(i, j) ((i) * ((i) + 1) / 2 + (j))
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        double d = g[GI(j, j)];
+#pragma unroll
+        for (int p = 0; p < j; ++p) d -= g[GI(j, p)] * g[GI(j, p)];
+        d = sqrt(d);
+        g[GI(j, j)] = d;
+        const double inv = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; ++i) {
+            double s = g[GI(i, j)];
+#pragma unroll
+            for (int p = 0; p < j; ++p) s -= g[GI(i, p)] * g[GI(j, p)];
+            g[GI(i, j)] = s * inv;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {   // L y = b
+        double s = b[i];
+#pragma unroll
+        for (int p = 0; p < i; ++p) s -= g[GI(i, p)] * b[p];
+        b[i] = s / g[GI(i, i)];
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {  // L^T x = y
+        double s = b[i];
+#pragma unroll
+        for (int p = i + 1; p < 6; ++p) s -= g[GI(p, i)] * b[p];
+        b[i] = s / g[GI(i, i)];
+    }
+#undef GI
+    const float A = (float)(b[0] * s2), B = (float)(b[1] * s2), C = (float)(b[2] * s2);
+    const float D = (float)(b[3] * s1), E = (float)(b[4] * s1), F = (float)b[5];
+    float* co = a.coefs + out * 6;
+    co[0] = A; co[1] = B; co[2] = C; co[3] = D; co[4] = E; co[5] = F;
+
+    float Kg, Kh;
+    monge_curvatures(A, B, C, D, E, Kg, Kh);
+    a.K[out] = Kg;
+    a.H[out] = Kh;
+    a.H2[out] = Kh * Kh;
+}
+
+// calculate_explicit_quadratic_curvatures alone (pct:398-431), one thread per row
+__global__ __launch_bounds__(256) void k_curv(const float* __restrict__ coefs, int64_t rows, float* __restrict__ K,
+                                              float* __restrict__ H, float* __restrict__ H2) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const float* c = coefs + r * 6;
+    float Kg, Kh;
+    monge_curvatures(c[0], c[1], c[2], c[3], c[4], Kg, Kh);
+    K[r] = Kg;
+    H[r] = Kh;
+    H2[r] = Kh * Kh;
+}
+
+int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
+    FitArgs a = a0;
+    a.kp = a.k | 1;
+    const size_t lds = (size_t)kFitBlock * a.kp * sizeof(int);
+    const int blocks = (int)((a.rows + kFitBlock - 1) / kFitBlock);
+    if (blocks <= 0) return PCT_OK;
+    if (f64)
+        hipLaunchKernelGGL(k_fit<true>, dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+    else
+        hipLaunchKernelGGL(k_fit<false>, dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+}  // namespace
+
+// fit from the device-resident neighbour table left by the sweep
+int pct_launch_fit_table(pct_ctx* ctx) {
+    const int64_t n = ctx->n;
+    const int64_t nq = ctx->q_end - ctx->q_begin;
+    PCT_TRY(pct_reserve(ctx, &ctx->coefs, (size_t)nq * 6 * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)nq * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->H, (size_t)nq * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->H2, (size_t)nq * sizeof(float)));
+    FitArgs a = {};
+    const bool sorted = ctx->knn_sorted_space;
+    a.pts = (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p);
+    a.ptsd = ctx->has_f64 ? (const double4*)(sorted ? ctx->sorted4d.p : ctx->pts4d.p) : nullptr;
+    a.table = (const int*)ctx->nbr_pos.p;
+    a.cnt = ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr;
+    a.row_query = nullptr;
+    a.rows = n;
+    a.k = ctx->k;
+    a.out_by_row = 0;
+    a.out_base = ctx->q_begin;
+    a.q_begin = (int)ctx->q_begin;
+    a.q_end = (int)ctx->q_end;
+    a.coefs = (float*)ctx->coefs.p;
+    a.K = (float*)ctx->K.p;
+    a.H = (float*)ctx->H.p;
+    a.H2 = (float*)ctx->H2.p;
+    return launch(ctx, a, ctx->has_f64);
+}
+
+// fit from caller-supplied neighbour rows (public indices), outputs row-aligned
+int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query,
+                        int64_t rows, int32_t k, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
+    FitArgs a = {};
+    a.pts = (const float4*)ctx->pts4.p;
+    a.ptsd = ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr;
+    a.table = d_idx;
+    a.cnt = d_cnt;
+    a.row_query = d_query;
+    a.rows = rows;
+    a.k = k;
+    a.out_by_row = 1;
+    a.out_base = 0;
+    a.q_begin = 0;
+    a.q_end = (int)ctx->n;
+    a.coefs = d_coefs;
+    a.K = d_K;
+    a.H = d_H;
+    a.H2 = d_H2;
+    return launch(ctx, a, ctx->has_f64);
+}
+
+int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2) {
+    const int blocks = (int)((rows + 255) / 256);
+    if (blocks <= 0) return PCT_OK;
+    hipLaunchKernelGGL(k_curv, dim3(blocks), dim3(256), 0, ctx->stream, d_coefs, rows, d_K, d_H, d_H2);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}

@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/pct_hip.h"
+
+#define PCT_WAVE 64
+
+// ---------------------------------------------------------------------------
+// Uniform cell list over the float32-rounded cloud.
+// Cell id = (cz * ny + cy) * nx + cx; cell coordinates are computed in fp64 so
+// that the "distance to the stencil boundary >= ring * cell" guarantee holds.
+// ---------------------------------------------------------------------------
+struct pct_grid {
+    double ox, oy, oz;      // origin (bbox min)
+    double cell;            // edge length
+    double inv_cell;
+    int32_t nx, ny, nz;
+    int64_t ncell;
+};
+
+struct pct_buf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+struct pct_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    char err[512] = {0};
+
+    int64_t n = 0;                 // cloud size (candidates)
+    int64_t q_begin = 0, q_end = 0;
+    bool has_f64 = false;
+    double occupancy_factor = 0.0; // 0 = default
+
+    // coordinates
+    pct_buf xyz;        // float  (n,3) public order
+    pct_buf pts4;       // float4 (n) public order, w = own index bits
+    pct_buf pts4d;      // double4 (n) public order (only when has_f64), w = index
+    // grid
+    pct_grid grid = {};
+    pct_buf cell_of;    // int32 (n) cell id per public point
+    pct_buf cell_cnt;   // int32 (ncell+1) counts -> exclusive starts
+    pct_buf cell_fill;  // int32 (ncell) scatter cursors
+    pct_buf scan_tmp;   // block sums
+    pct_buf occ;        // int32 (n_occ) occupied cell ids
+    pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
+    pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
+    pct_buf red;        // small reduction scratch
+    int64_t n_occ = 0;
+    bool grid_valid = false;
+    bool pts4_valid = false;
+
+    // neighbour table in sorted space: row = sorted position of the query
+    pct_buf nbr_pos;    // int32 (n,k) sorted positions of the neighbours
+    pct_buf nbr_dist;   // float (n,k)
+    pct_buf nbr_cnt;    // int32 (n)
+    int32_t k = 0;
+    double eps = 0.0;
+    bool knn_valid = false;
+    bool knn_sorted_space = false; // false: rows/ids are public indices (brute force)
+    pct_buf counters;   // int64[4] device counters (fallbacks, overflows)
+
+    // results, public order
+    pct_buf coefs;      // float (n,6)
+    pct_buf K, H, H2;   // float (n)
+    int64_t fit_rows = 0;
+    bool fit_valid = false;
+
+    // staging for downloads / host-index fits
+    pct_buf stage_a, stage_b, stage_c, stage_d;
+
+    pct_timings tm = {};
+};
+
+int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...);
+int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);
+
+#define PCT_HIP(ctx, call)                                                        \
+    do {                                                                          \
+        hipError_t e_ = (call);                                                   \
+        if (e_ != hipSuccess)                                                     \
+            return pct_fail((ctx), e_ == hipErrorOutOfMemory ? PCT_ERR_OOM : PCT_ERR_HIP, \
+                            "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+#define PCT_TRY(expr)            \
+    do {                         \
+        int s_ = (expr);         \
+        if (s_ != PCT_OK) return s_; \
+    } while (0)
+
+// grid build (pct_grid.hip)
+int pct_pack_points(pct_ctx* ctx, float* bbox6);
+int pct_pack_points_f64(pct_ctx* ctx, const double* d_xyz64);
+int pct_build_grid(pct_ctx* ctx, int32_t k, double eps);
+// neighbour sweeps (pct_knn.hip)
+int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps);
+int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
+int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
+                                int32_t* d_idx, float* d_dist, int32_t* d_cnt);
+// fit (pct_fit.hip)
+int pct_launch_fit_table(pct_ctx* ctx);
+int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt,
+                        const int64_t* d_query, int64_t rows, int32_t k,
+                        float* d_coefs, float* d_K, float* d_H, float* d_H2);
+int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);

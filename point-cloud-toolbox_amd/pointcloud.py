@@ -1,0 +1,206 @@
+"""MI355X-backed ``PointCloud``: the reference's class surface for the curvature path.
+
+Mirrors /root/reference/pointCloudToolbox.py:24-1009 for the methods on the hot
+path: same constructor signature, same attribute names,
+same curvature-array outputs, same exception types and messages.  The work is
+done by hand-written HIP kernels behind the C ABI of ``include/pct_hip.h``;
+there is no CPU fallback -- without the shared library or a gfx950 device the
+compute methods raise.
+
+Deliberate, documented differences (none changes a value):
+* ``neighbor_indices`` / ``dists`` stay on the device and are downloaded on first
+  access (400 MB at 1 M points, k=50);
+* ``quadratic_coefficients`` is an (N, 6) float32 array and ``K_quadratic`` /
+  ``H_quadratic`` / ``K_H_sq_quadratic`` are (N,) float32 arrays instead of
+  Python lists of the same float32 values (pct:637, pct:659-661); every use in
+  the reference's callers (len, indexing, np.save, np.isnan, iteration) works
+  on both.
+"""
+from __future__ import annotations
+
+import gc
+
+import numpy as np
+
+from . import _capi
+
+__all__ = ["PointCloud"]
+
+
+class PointCloud:
+
+    # pct:26 -- identical signature and defaults
+    def __init__(self, file_path=None, points=None, normals=None, downsample=False, voxel_size=0,
+                 k_neighbors=20, output_path='./output/', max_points_per_voxel=1, device=0):
+        self.downsample = downsample
+        self.k_neighbors = k_neighbors
+        self.voxel_size = voxel_size
+        self.max_points_per_voxel = max_points_per_voxel
+        self.output_path = output_path
+        self.random_indexes = []
+        self._device = device
+        self._handle = None
+        self._cloud_on_device = False
+        self._nbr_cache = None
+        self._user_neighbors = None
+        self._fit_on_device = False
+        self.eps = None
+
+        if file_path:
+            self.file_path = file_path
+            self.read_from_file()
+        elif points is not None and normals is not None:
+            self.points = points
+            self.normals = normals
+        else:
+            raise ValueError("Either file_path or points and normals must be provided")      # pct:41
+
+        # pct:43-47
+        self.num_points = len(self.points)
+        self.num_features = len(self.points[0])
+        self.l1_norm = np.linalg.norm(self.points, 1)
+        self.l2_norm = np.linalg.norm(self.points, 2)
+        self.infinity_norm = np.linalg.norm(self.points, np.inf)
+
+    # pct:50-66
+    def read_from_file(self):
+        points = np.loadtxt(self.file_path)
+        self.points = points[:, 0:3].astype(np.float32)
+        self.normals = points[:, 3:6].astype(np.float32)
+        gc.collect()
+        self.points[:, 0] -= np.max(self.points[:, 0])
+        self.points[:, 1] -= np.max(self.points[:, 1])
+        if self.downsample:
+            # pct:59-60 calls a method the reference has commented out (pct:159-193)
+            raise AttributeError("'PointCloud' object has no attribute 'downsample_point_cloud_by_grid'")
+        self.x_domain = [np.min(self.points[:, 0]), np.max(self.points[:, 0])]
+        self.y_domain = [np.min(self.points[:, 1]), np.max(self.points[:, 1])]
+        self.z_domain = [np.min(self.points[:, 2]), np.max(self.points[:, 2])]
+
+    # ---------------------------------------------------------------- device
+    def _ctx(self):
+        if self._handle is None:
+            self._handle = _capi.Handle(self._device)      # raises without library / GPU
+        if not self._cloud_on_device:
+            pts = np.asarray(self.points)
+            if pts.ndim != 2 or pts.shape[1] != 3:
+                raise ValueError("points must have shape (N, 3)")
+            if pts.dtype != np.float64:
+                pts = pts.astype(np.float32, copy=False)
+            self._handle.set_points(pts)
+            self._cloud_on_device = True
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+            self._cloud_on_device = False
+
+    # ------------------------------------------------------------------ A3
+    def plant_kdtree(self, k_neighbors, eps=None, algorithm="auto"):
+        """k-NN table for every point (pct:69-89), computed on the GPU.
+
+        ``eps`` (extension, README.md:8 / SURVEY A11): hybrid query, at most k
+        neighbours with distance < eps; ``neighbor_counts`` then holds the
+        number of valid entries per row.
+        """
+        self.k_neighbors = k_neighbors                      # pct:71
+        self.eps = eps
+        algo = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID}[algorithm]
+        h = self._ctx()
+        h.knn(k_neighbors, eps or 0.0, algo)
+        self._nbr_cache = None
+        self._user_neighbors = None
+        self._fit_on_device = False
+        self.last_timings = h.timings()
+
+    def _download_neighbors(self):
+        if self._nbr_cache is None:
+            if self._handle is None or not hasattr(self._handle, "k"):
+                raise AttributeError("'PointCloud' object has no attribute 'neighbor_indices'")
+            idx, dist, cnt = self._handle.get_neighbors(0, self.num_points, True, True, True)
+            self._nbr_cache = (idx, dist, cnt)
+        return self._nbr_cache
+
+    @property
+    def neighbor_indices(self):
+        """(N, k) int32, rows ascending by distance, self excluded (pct:79, 85)."""
+        if self._user_neighbors is not None:
+            return self._user_neighbors
+        return self._download_neighbors()[0]
+
+    @neighbor_indices.setter
+    def neighbor_indices(self, value):
+        self._user_neighbors = np.asarray(value)
+        self._fit_on_device = False
+
+    @property
+    def dists(self):
+        """(N, k) float32 (pct:78, 84)."""
+        return self._download_neighbors()[1]
+
+    @property
+    def neighbor_counts(self):
+        return self._download_neighbors()[2]
+
+    # ------------------------------------------------------------------ A4
+    def fit_explicit_quadratic_surfaces_to_neighborhoods(self):
+        """Plane-align + quadric fit of every neighbourhood (pct:635-647)."""
+        h = self._ctx()
+        if self._user_neighbors is not None:
+            h.fit_indices(self._user_neighbors)
+        else:
+            h.fit()                                          # AttributeError if no table (pct:640)
+        coefs, K, H, H2 = h.get_fit(0, self.num_points)
+        self.quadratic_coefficients = coefs
+        self._device_curv = (K, H, H2)
+        self._fit_on_device = True
+        self.last_timings = h.timings()
+
+    # ------------------------------------------------------------------ A8
+    def calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points(self):
+        """K, H, H^2 from the fitted coefficients (pct:657-674)."""
+        if self._fit_on_device and self._device_curv is not None:
+            K, H, H2 = self._device_curv                     # produced by the fused kernel
+        else:
+            K, H, H2 = self._ctx().curvatures_from_coefficients(np.asarray(self.quadratic_coefficients))
+        self.K_quadratic = K
+        self.H_quadratic = H
+        self.K_H_sq_quadratic = H2
+        return self.K_quadratic, self.H_quadratic
+
+    # ------------------------------------------------------------------ A9
+    def compute_pointwise_explicit_quadratic_curvature(self):
+        """pct:505-509."""
+        self.fit_explicit_quadratic_surfaces_to_neighborhoods()
+        K, H = self.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
+        return np.array(K), np.array(H)
+
+    # fused entry: k-NN -> fit -> curvature with nothing but K/H leaving the GPU
+    def compute_curvature_fused(self, k_neighbors, eps=None, algorithm="auto"):
+        self.k_neighbors = k_neighbors
+        self.eps = eps
+        algo = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID}[algorithm]
+        h = self._ctx()
+        h.curvature(k_neighbors, eps or 0.0, algo)
+        self._nbr_cache = None
+        self._user_neighbors = None
+        _, K, H, H2 = h.get_fit(0, self.num_points, coefs=False)
+        self.K_quadratic, self.H_quadratic, self.K_H_sq_quadratic = K, H, H2
+        self.last_timings = h.timings()
+        return K, H
+
+    # --------------------------------------------------------- staticmethods
+    @staticmethod
+    def calculate_explicit_quadratic_curvatures(coefficients):
+        """pct:398-431 for one coefficient vector (device evaluation)."""
+        h = _capi.Handle(0)
+        try:
+            c = np.asarray(coefficients, dtype=np.float32).reshape(1, 6)
+            K, H, H2 = h.curvatures_from_coefficients(c)
+        finally:
+            h.close()
+        disc = max(H[0] ** 2 - K[0], 0)                      # pct:425
+        root = np.sqrt(disc)
+        return K[0], H[0], H[0] + root, H[0] - root, H2[0]

@@ -1,0 +1,112 @@
+"""Seeded synthetic clouds for parity tests and the bench.
+
+The formulas restate the reference's shape generators
+(/root/reference/utils.py:858-866 Fibonacci sphere, :888-896 torus with R=1,
+r=1/3, :911-914 egg carton 0.1 sin(pi x) cos(pi y)); sampling is this build's
+own: float64 maths, ``np.random.default_rng(seed)`` (PCG64), one cast to
+float32 at the end.  Closed-form curvatures are returned next to the points so
+tests can compare against them (plot_shape_validation_results.py:28-45).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+TORUS_R = 1.0
+TORUS_r = 1.0 / 3.0
+
+
+def fibonacci_sphere(n, radius=1.0, dtype=np.float32):
+    """Fibonacci lattice (utils.py:859-865): K = 1/r^2, H = 1/r."""
+    i = np.arange(n, dtype=np.float64) + 0.5
+    phi = np.arccos(1.0 - 2.0 * i / n)
+    theta = np.pi * (1.0 + 5.0 ** 0.5) * i
+    p = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], 1) * radius
+    return p.astype(dtype)
+
+
+def torus_angles(n, seed=1234, lo=0, hi=None):
+    """(theta, phi) ~ U[0, 2pi)^2 for rows [lo, hi) of the n-point cloud.
+
+    The stream is drawn in fixed blocks so that any index range can be
+    regenerated without materialising the whole cloud (multi-GPU shards).
+    """
+    hi = n if hi is None else hi
+    blk = 1 << 20
+    out = np.empty((hi - lo, 2), dtype=np.float64)
+    b0, b1 = lo // blk, (max(hi, lo + 1) - 1) // blk
+    for b in range(b0, b1 + 1):
+        rng = np.random.default_rng([seed, b])
+        m = min(blk, n - b * blk)
+        ang = rng.uniform(0.0, 2.0 * np.pi, size=(m, 2))
+        s, e = max(lo, b * blk), min(hi, b * blk + m)
+        if e > s:
+            out[s - lo:e - lo] = ang[s - b * blk:e - b * blk]
+    return out
+
+
+def torus_from_angles(ang, R=TORUS_R, r=TORUS_r, dtype=np.float32):
+    th, ph = ang[:, 0], ang[:, 1]
+    w = R + r * np.cos(ph)
+    p = np.stack([w * np.cos(th), w * np.sin(th), r * np.sin(ph)], 1)
+    return p.astype(dtype)
+
+
+def torus_random(n, seed=1234, R=TORUS_R, r=TORUS_r, dtype=np.float32, lo=0, hi=None, with_truth=False):
+    """Random-parameter torus (primary, tie-free bench input)."""
+    ang = torus_angles(n, seed, lo, hi)
+    p = torus_from_angles(ang, R, r, dtype)
+    if not with_truth:
+        return p
+    cph = np.cos(ang[:, 1])
+    K = cph / (r * (R + r * cph))
+    H = (R + 2.0 * r * cph) / (2.0 * r * (R + r * cph))
+    return p, K, H
+
+
+def torus_grid(n_side, R=TORUS_R, r=TORUS_r, dtype=np.float32):
+    """Reference-style theta x phi lattice (utils.py:888-896); many k-NN ties."""
+    t = np.linspace(0.0, 2.0 * np.pi, n_side)
+    th, ph = np.meshgrid(t, t)
+    return torus_from_angles(np.stack([th.ravel(), ph.ravel()], 1), R, r, dtype)
+
+
+def egg_carton_random(n, seed=1234, amp=0.1, dtype=np.float32, lo=0, hi=None, with_truth=False):
+    """(x, y) ~ U[-1, 1]^2, z = amp sin(pi x) cos(pi y) (utils.py:911-914)."""
+    hi = n if hi is None else hi
+    blk = 1 << 20
+    xy = np.empty((hi - lo, 2), dtype=np.float64)
+    b0, b1 = lo // blk, (max(hi, lo + 1) - 1) // blk
+    for b in range(b0, b1 + 1):
+        rng = np.random.default_rng([seed, 7, b])
+        m = min(blk, n - b * blk)
+        u = rng.uniform(-1.0, 1.0, size=(m, 2))
+        s, e = max(lo, b * blk), min(hi, b * blk + m)
+        if e > s:
+            xy[s - lo:e - lo] = u[s - b * blk:e - b * blk]
+    x, y = xy[:, 0], xy[:, 1]
+    z = amp * np.sin(np.pi * x) * np.cos(np.pi * y)
+    p = np.stack([x, y, z], 1).astype(dtype)
+    if not with_truth:
+        return p
+    pi = np.pi
+    fx = amp * pi * np.cos(pi * x) * np.cos(pi * y)
+    fy = -amp * pi * np.sin(pi * x) * np.sin(pi * y)
+    fxx = -amp * pi * pi * np.sin(pi * x) * np.cos(pi * y)
+    fyy = fxx
+    fxy = -amp * pi * pi * np.cos(pi * x) * np.sin(pi * y)
+    w = 1.0 + fx * fx + fy * fy
+    K = (fxx * fyy - fxy * fxy) / w ** 2
+    H = ((1 + fx * fx) * fyy - 2 * fx * fy * fxy + (1 + fy * fy) * fxx) / (2 * w ** 1.5)
+    return p, K, H
+
+
+def tile_cloud(base, n_tiles, pitch=0.25, lattice=(9, 8, 8), dtype=np.float32):
+    """Translated copies of ``base`` on a lattice (bunny x 557)."""
+    base = np.asarray(base, dtype=np.float64)
+    base = base - base.min(0)
+    out = np.empty((n_tiles * len(base), 3), dtype=dtype)
+    nx, ny, _ = lattice
+    for t in range(n_tiles):
+        off = np.array([t % nx, (t // nx) % ny, t // (nx * ny)], dtype=np.float64) * pitch
+        out[t * len(base):(t + 1) * len(base)] = (base + off).astype(dtype)
+    return out
