@@ -1,0 +1,168 @@
+"""Headline bench: points/s of Gaussian+mean curvature (BASELINE.json metric).
+
+Workload (config.workload): synthetic torus R=1, r=1/3, random (theta, phi), seed 1234, float32,
+1 000 000 points PER GPU at k=50 (BASELINE configs[2]; weak scaling: N ranks hold an N-million-point
+torus, rank r owns index range r).  One "step" = one full pass of the hot path over the resident
+cloud: [N>1: RCCL all-gather of the coordinate shards] -> cell-list build -> k-NN sweep -> fused
+plane-align / quadric fit / K,H.  Inputs are in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (see README/DESIGN.md for the field definitions).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(pts, k, seconds_target=15.0):
+    """1-core reference-faithful port (oracle loop) on a bounded sample of the same cloud."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pct_oracle as oracle
+    from scipy.spatial import cKDTree
+    n = len(pts)
+    rng = np.random.default_rng(7)
+    tree = cKDTree(np.array(pts, dtype=np.float32))           # build is excluded, as the GPU's upload is
+    probe = rng.choice(n, 2000, replace=False)
+    t0 = time.perf_counter()
+    _run_loop(oracle, tree, pts, probe, k)
+    rate = 2000 / (time.perf_counter() - t0)
+    m = int(min(n, max(2000, rate * seconds_target)))
+    rows = rng.choice(n, m, replace=False)
+    t0 = time.perf_counter()
+    _run_loop(oracle, tree, pts, rows, k)
+    dt = time.perf_counter() - t0
+    return {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
+            "sample": f"{m} random rows of the same {n}-point torus, k={k}, per-point loop "
+                      f"(cKDTree.query + cov/svd + lstsq, oracle/pct_oracle.py), tree build excluded, {dt:.1f} s"}
+
+
+def _run_loop(oracle, tree, pts, rows, k):
+    for i in rows:
+        d, nb = tree.query(pts[i], k + 1)
+        c = oracle.quadric_fit(oracle.plane_align(pts[nb[1:]] - pts[i]))
+        oracle.quadric_curvatures(c)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--k", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+
+    import __graft_entry__ as ge
+    ge.build()
+    from point_cloud_toolbox_amd import _capi, shapes
+    from point_cloud_toolbox_amd.dist import ShardedCurvature, shard_range
+
+    k = args.k
+    n_total = args.points_per_gpu * world
+    lo, hi = shard_range(n_total, rank, world)
+    local = shapes.torus_random(n_total, seed=1234, lo=lo, hi=hi)
+
+    dist = torch = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    handle = _capi.Handle(local_rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        handle.synchronize()
+
+    if world == 1:
+        handle.set_points(local)                              # resident before the timed region
+
+        def step():
+            handle.curvature(k, 0.0, _capi.KNN_GRID)
+    else:
+        dev = torch.device("cuda", local_rank)
+        sc = ShardedCurvature(n_total, k, rank, world, handle=handle, device=dev)
+        sizes = {shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)}
+        assert len(sizes) == 1, "bench shards are equal-sized"
+        # the local shard is resident on the device before the timed region; the exchange is part of the step
+        local_dev = torch.from_numpy(local).to(dev)
+        full_buf = torch.empty((n_total, 3), dtype=torch.float32, device=dev)
+
+        def step():
+            dist.all_gather_into_tensor(full_buf, local_dev)  # RCCL over xGMI: 12 B/point per rank
+            sc.run_device(full_buf)
+
+    for _ in range(args.warmup):
+        step()
+    knn_ms = fit_ms = grid_ms = 0.0
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        tm = handle.timings()                                 # hipEvent times recorded on the handle's stream
+        knn_ms += tm["knn_ms"]; fit_ms += tm["fit_ms"]; grid_ms += tm["grid_ms"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        steps = args.steps
+        nq = hi - lo
+        knn_avg_s = knn_ms / steps / 1e3
+        algo_bytes = nq * (12 + 8 * k)                        # B_knn(k) = 12 + 8k per point
+        achieved = algo_bytes / knn_avg_s / 1e9
+        out = {
+            "metric": "points/sec curvature (1M-pt torus, k=50); HBM GB/s k-NN vs peak",
+            "value": n_total * steps / dt,
+            "unit": "points/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"synthetic torus R=1 r=1/3, random (theta,phi) seed 1234, float32, "
+                                   f"{args.points_per_gpu} points per GPU ({n_total} total), k={k}, grid k-NN + "
+                                   "fused plane-align/quadric-fit/curvature (BASELINE configs[2])",
+                       "points_total": n_total, "k": k,
+                       "parallelism": f"point-index-range shards x{world}" + (" + RCCL all-gather of coordinates" if world > 1 else "")},
+            "roofline": {"bound": "hbm", "kernel": "k_knn_grid", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": knn_ms / steps},
+            "stage_ms": {"grid_build": grid_ms / steps, "knn": knn_ms / steps, "fit_curvature": fit_ms / steps},
+            "target_points_per_s": 1e7,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(local, k)
+            out["cpu_baseline"]["host_cpus"] = os.cpu_count()
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    handle.close()
+
+
+if __name__ == "__main__":
+    main()

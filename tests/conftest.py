@@ -1,0 +1,41 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    def load(name):
+        return dict(np.load(os.path.join(GOLDEN, name)))   # allow_pickle stays False
+    return load
+
+
+@pytest.fixture(scope="session")
+def built():
+    """Build (or reuse) the HIP extension and return the package modules."""
+    import __graft_entry__ as ge
+    ge.build()
+    import pointCloudToolbox
+    from point_cloud_toolbox_amd import _capi, shapes
+    return dict(PointCloud=pointCloudToolbox.PointCloud, capi=_capi, shapes=shapes)
+
+
+@pytest.fixture(scope="session")
+def gpu(built):
+    capi = built["capi"]
+    if capi.device_count() < 1:
+        pytest.fail("-m gpu tests need a GPU: pct_device_count() == 0 (no CPU fallback exists)")
+    return built

@@ -1,0 +1,296 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference goldens.
+
+Bars:  neighbour indices / float32 distances bit-exact;
+K, H:  |x - ref| <= 1e-5 * max(|ref|, 1e-2 * scale)  with scale = max|ref| of the input.
+"""
+import numpy as np
+import pytest
+
+import pct_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-5          # north-star tolerance (float64 reference, relative)
+FLOOR = 1e-2         # absolute floor as a fraction of the input's curvature scale
+
+
+def assert_curvature(K, H, refK, refH, mask=None):
+    fK, fH = FLOOR * np.nanmax(np.abs(refK)), FLOOR * np.nanmax(np.abs(refH))
+    okK = oracle.curvature_tolerance_ok(K, refK, fK, RTOL)
+    okH = oracle.curvature_tolerance_ok(H, refH, fH, RTOL)
+    if mask is not None:
+        okK, okH = okK | ~mask, okH | ~mask
+    assert okK.all(), f"K: {np.count_nonzero(~okK)} rows outside 1e-5 (worst {np.nanmax(np.abs(K - refK)):.3e})"
+    assert okH.all(), f"H: {np.count_nonzero(~okH)} rows outside 1e-5 (worst {np.nanmax(np.abs(H - refH)):.3e})"
+
+
+def run_cloud(gpu, pts, k, algorithm="auto", eps=None):
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(k, eps=eps, algorithm=algorithm)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    return pc, K, H
+
+
+# ------------------------------------------------------------------ goldens
+@pytest.mark.parametrize("name", ["g1_sphere2k_k30.npz", "g2_torus4k_k50.npz", "g3_egg4k_k50.npz"])
+@pytest.mark.parametrize("algorithm", ["brute", "grid"])
+def test_reference_goldens(gpu, golden, name, algorithm):
+    g = golden(name)
+    pc, K, H = run_cloud(gpu, g["points"], int(g["k"]), algorithm)
+    assert pc.neighbor_indices.dtype == np.int32 and pc.dists.dtype == np.float32
+    assert np.array_equal(pc.neighbor_indices, g["idx"])
+    assert np.array_equal(pc.dists, g["dists"])
+    assert K.dtype == np.float32 and H.dtype == np.float32 and K.shape == (len(g["points"]),)
+    assert_curvature(K, H, g["K"], g["H"])
+    assert_curvature(pc.K_H_sq_quadratic, H, g["H2"], g["H"])
+    co = np.asarray(pc.quadratic_coefficients)
+    assert co.shape == (len(K), 6) and co.dtype == np.float32
+    assert (co == g["coefs"]).all(1).mean() > 0.99            # float32 rounding of an fp64 solve
+    assert len(pc.K_quadratic) == len(K) and pc.K_quadratic[3] == K[3]
+
+
+def test_file_constructor_golden(gpu, golden, tmp_path):
+    g = golden("g4_bunny4k_file_k30.npz")
+    f = tmp_path / "scan.txt"
+    np.savetxt(f, g["raw"])
+    pc = gpu["PointCloud"](str(f))
+    pc.plant_kdtree(30)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    assert np.array_equal(pc.neighbor_indices, g["idx"]) and np.array_equal(pc.dists, g["dists"])
+    assert_curvature(K, H, g["K"], g["H"])
+
+
+def test_regular_grid_ties(gpu, golden):
+    """Exact lattice (sample_scans/egg_carton.txt corner): k-th/(k+1)-th distances tie."""
+    g = golden("g5_egggrid64_k30.npz")
+    pc, K, H = run_cloud(gpu, g["points"], 30, "grid")
+    assert np.array_equal(pc.dists, g["dists"])               # sorted distance rows are tie-independent
+    same = (pc.neighbor_indices == g["idx"]).all(1)
+    same_set = np.array([set(a) == set(b) for a, b in zip(pc.neighbor_indices, g["idx"])])
+    # rows may differ from cKDTree's arbitrary tie order only where equal distances occur
+    for i in np.where(~same)[0]:
+        diff = pc.neighbor_indices[i] != g["idx"][i]
+        d = g["dists"][i]
+        for j in np.where(diff)[0]:
+            assert (d == d[j]).sum() >= 2 or j == 29
+    assert_curvature(K, H, g["K"], g["H"], mask=same)
+    # identical indices in -> contract out, for every row
+    pc.neighbor_indices = g["idx"]
+    K2, H2 = pc.compute_pointwise_explicit_quadratic_curvature()
+    assert_curvature(K2, H2, g["K"], g["H"])
+    assert same_set.mean() > 0.9
+
+
+def test_unit_neighbourhood_branches(gpu, golden):
+    """G6: plane (s == 0 branch, pct:308), paraboloids (orientation), saddle, tilted patch."""
+    g = golden("g6_unit_cases.npz")
+    capi = gpu["capi"]
+    h = capi.Handle(0)
+    for n in sorted(k[:-3] for k in g if k.endswith("_in")):
+        nb = g[n + "_in"]
+        cloud = np.vstack([np.zeros((1, 3), nb.dtype), nb])   # query at the origin, neighbours as given
+        h.set_points(cloud)
+        h.fit_indices(np.arange(1, len(cloud), dtype=np.int32)[None, :], query=np.array([0]))
+        co, K, H, H2 = h.get_fit(0, 1)
+        ref = g[n + "_curv"]
+        scale = max(1.0, float(np.abs(g[n + "_coefs"][:3]).max()))
+        assert np.allclose(co[0], g[n + "_coefs"], rtol=1e-5, atol=2e-6 * scale), n
+        assert abs(K[0] - ref[0]) <= 1e-5 * max(abs(ref[0]), 1e-2 * scale * scale), n
+        assert abs(H[0] - ref[1]) <= 1e-5 * max(abs(ref[1]), 1e-2 * scale), n
+    h.close()
+
+
+# ------------------------------------------------------- seeded vs the oracle
+@pytest.mark.parametrize("k", [6, 30, 50, 63, 64, 80, 100, 127])
+def test_knn_k_sweep(gpu, k):
+    pts = gpu["shapes"].torus_random(20_000, seed=100 + k)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(k, algorithm="grid")
+    idx, d = oracle.knn(pts, k)
+    assert np.array_equal(pc.neighbor_indices, idx) and np.array_equal(pc.dists, d)
+    assert (np.diff(pc.dists, axis=1) >= 0).all()
+    assert (pc.neighbor_indices != np.arange(len(pts))[:, None]).all()      # self dropped (pct:84-85)
+
+
+def test_brute_and_grid_agree_bitwise(gpu):
+    pts = gpu["shapes"].egg_carton_random(30_000, seed=8)
+    a, Ka, Ha = run_cloud(gpu, pts, 50, "brute")
+    b, Kb, Hb = run_cloud(gpu, pts, 50, "grid")
+    assert np.array_equal(a.neighbor_indices, b.neighbor_indices) and np.array_equal(a.dists, b.dists)
+    assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
+
+
+@pytest.mark.parametrize("shape,k", [("sphere", 30), ("torus", 50), ("egg", 50)])
+def test_pipeline_vs_oracle_100k(gpu, shape, k):
+    sh = gpu["shapes"]
+    pts = {"sphere": lambda: sh.fibonacci_sphere(100_000), "torus": lambda: sh.torus_random(100_000, seed=31),
+           "egg": lambda: sh.egg_carton_random(100_000, seed=32)}[shape]()
+    pc, K, H = run_cloud(gpu, pts, k)
+    ref = oracle.pipeline_batched(pts, k)
+    assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
+    assert_curvature(K, H, ref["K"], ref["H"])
+    if shape == "sphere":     # closed form K = H = 1 up to the estimator's own O(h^2) bias
+        assert np.abs(K - 1).max() < 2e-3 and np.abs(H - 1).max() < 2e-3
+
+
+def test_float64_cloud_native_dtype(gpu):
+    """float64 points: float32-rounded tree, float64 queries and centring (pct:74, 83, 641)."""
+    pts = gpu["shapes"].torus_random(20_000, seed=77, dtype=np.float64)
+    pc, K, H = run_cloud(gpu, pts, 40)
+    ref = oracle.pipeline_batched(pts, 40)
+    assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
+    assert_curvature(K, H, ref["K"], ref["H"])
+
+
+def test_hybrid_eps_query(gpu):
+    pts = gpu["shapes"].egg_carton_random(20_000, seed=4)
+    pc, K, H = run_cloud(gpu, pts, 50, eps=0.06)
+    ref = oracle.pipeline_batched(pts, 50, eps=0.06)
+    assert np.array_equal(pc.neighbor_counts, ref["count"])
+    assert 6 <= ref["count"].min() < 50 == ref["count"].max()           # both branches exercised
+    assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
+    assert_curvature(K, H, ref["K"], ref["H"])
+
+
+def test_density_contrast_forces_ring_fallback_and_lds_overflow(gpu):
+    rng = np.random.default_rng(5)
+    dense = rng.normal(scale=0.002, size=(6000, 3))
+    sparse = rng.uniform(-1, 1, size=(3000, 3))
+    pts = np.vstack([dense, sparse]).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(50, algorithm="grid")
+    t = pc.last_timings
+    idx, d = oracle.knn(pts, 50)
+    assert np.array_equal(pc.neighbor_indices, idx) and np.array_equal(pc.dists, d)
+    assert t["ring_fallbacks"] > 0 and t["lds_overflows"] > 0
+
+
+def test_duplicate_points(gpu):
+    pts = gpu["shapes"].torus_random(5000, seed=2)
+    pts[100:200] = pts[0:100]                                  # exact twins
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(20, algorithm="grid")
+    _, d = oracle.knn(pts, 20)
+    assert np.array_equal(pc.dists, d)                         # tie order is arbitrary, distances are not
+    assert (pc.dists[0:200, 0] == 0).all()
+
+
+# ---------------------------------------------------------- full bench size
+def test_torus_1m_sampled_oracle_and_properties(gpu, golden):
+    """BASELINE config C3 at full size against the sampled reference golden G7."""
+    g = golden("g7_torus1m_k50_sample.npz")
+    sh = gpu["shapes"]
+    pts, Ktrue, Htrue = sh.torus_random(1_000_000, seed=1234, with_truth=True)
+    pc, K, H = run_cloud(gpu, pts, 50)
+    rows = g["rows"]
+    idx, d = pc.neighbor_indices, pc.dists
+    assert np.array_equal(idx[rows], g["idx"]) and np.array_equal(d[rows], g["dists"])
+    assert_curvature(K[rows], H[rows], g["K"], g["H"])
+    # size-independent properties on all 1M rows
+    assert (np.diff(d, axis=1) >= 0).all() and np.isfinite(d).all()
+    assert idx.min() >= 0 and idx.max() < len(pts)
+    assert (idx != np.arange(len(pts), dtype=np.int32)[:, None]).all()
+    rec = np.linalg.norm(pts[idx[::997, -1]].astype(np.float64) - pts[::997].astype(np.float64), axis=1)
+    assert np.array_equal(rec.astype(np.float32), d[::997, -1])          # distances re-derive from the indices
+    # closed form (plot_shape_validation_results.py:28-45 generalised over phi): estimator bias only
+    assert np.median(np.abs(K - Ktrue)) < 2e-2 and np.median(np.abs(H - Htrue)) < 1e-2
+
+
+def test_sphere_100k_sampled_golden(gpu, golden):
+    g = golden("g7_sphere100k_k30_sample.npz")
+    pts = gpu["shapes"].fibonacci_sphere(100_000)
+    pc, K, H = run_cloud(gpu, pts, 30)
+    rows = g["rows"]
+    assert np.array_equal(pc.neighbor_indices[rows], g["idx"]) and np.array_equal(pc.dists[rows], g["dists"])
+    assert_curvature(K[rows], H[rows], g["K"], g["H"])
+
+
+# ------------------------------------------------------------- boundary API
+def test_query_range_shards_are_bit_identical(gpu):
+    """Index-range sharding (multi-GPU ownership) does not change any value."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(40_000, seed=6)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.curvature(50)
+    i0, d0, _ = h.get_neighbors(0, len(pts))
+    _, K0, H0, _ = h.get_fit(0, len(pts))
+    parts = []
+    for lo, hi in [(0, 13_333), (13_333, 40_000)]:
+        h.set_query_range(lo, hi)
+        h.curvature(50)
+        i, d, _ = h.get_neighbors(lo, hi)
+        _, K, H, _ = h.get_fit(lo, hi)
+        parts.append((i, d, K, H))
+        with pytest.raises(ValueError):
+            h.get_fit(0, len(pts))
+    h.close()
+    for j, ref in enumerate((i0, d0, K0, H0)):
+        assert np.array_equal(np.concatenate([p[j] for p in parts]), ref)
+
+
+def test_fused_entry_matches_stepwise(gpu):
+    pts = gpu["shapes"].egg_carton_random(25_000, seed=9)
+    a, Ka, Ha = run_cloud(gpu, pts, 50)
+    b = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    Kb, Hb = b.compute_curvature_fused(50)
+    assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
+    assert b.last_timings["knn_ms"] > 0 and b.last_timings["fit_ms"] > 0
+
+
+def test_host_supplied_indices_and_validation(gpu, golden):
+    g = golden("g2_torus4k_k50.npz")
+    capi = gpu["capi"]
+    h = capi.Handle(0)
+    h.set_points(g["points"])
+    h.fit_indices(g["idx"])
+    co, K, H, H2 = h.get_fit(0, len(g["idx"]))
+    assert_curvature(K, H, g["K"], g["H"])
+    rows = np.array([5, 17, 3999])
+    h.fit_indices(g["idx"][rows], query=rows)
+    _, K2, H2_, _ = h.get_fit(0, 3)
+    assert np.array_equal(K2, K[rows]) and np.array_equal(H2_, H[rows])
+    bad = g["idx"].copy()
+    bad[7, 3] = len(g["points"])                             # IndexError in the reference (pct:640)
+    with pytest.raises(ValueError, match="out of range"):
+        h.fit_indices(bad)
+    h.close()
+
+
+def test_curvatures_from_coefficients(gpu, golden):
+    g = golden("g3_egg4k_k50.npz")
+    h = gpu["capi"].Handle(0)
+    K, H, H2 = h.curvatures_from_coefficients(g["coefs"])
+    h.close()
+    assert_curvature(K, H, g["K"], g["H"])
+    assert (K == g["K"]).mean() > 0.99 and (H2 == g["H2"]).mean() > 0.9
+    out = gpu["PointCloud"].calculate_explicit_quadratic_curvatures(g["coefs"][0])
+    ref = oracle.quadric_curvatures(g["coefs"][0])
+    assert np.allclose(out, ref, rtol=1e-6)
+
+
+def test_error_conventions(gpu):
+    PC = gpu["PointCloud"]
+    pts = gpu["shapes"].torus_random(500, seed=1)
+    bad = pts.copy()
+    bad[17, 2] = np.nan
+    with pytest.raises(ValueError, match="Non-finite values in input points"):      # pct:274
+        PC(points=bad, normals=np.zeros((500, 0))).plant_kdtree(10)
+    with pytest.raises(IndexError):                                                 # k+1 > N (pct:640)
+        PC(points=pts[:20], normals=np.zeros((20, 0))).plant_kdtree(20)
+    pc = PC(points=pts, normals=np.zeros((500, 0)))
+    with pytest.raises(AttributeError):                                             # no neighbor_indices yet
+        pc.fit_explicit_quadratic_surfaces_to_neighborhoods()
+    pc.plant_kdtree(19)                                                             # k+1 == 20 <= N is fine
+    small = PC(points=pts[:20], normals=np.zeros((20, 0)))
+    small.plant_kdtree(19)                                                          # k+1 == N exactly
+    i, d = oracle.knn(pts[:20], 19)
+    assert np.array_equal(small.neighbor_indices, i) and np.array_equal(small.dists, d)
+
+
+def test_k_neighbors_overwritten_by_plant(gpu):
+    pts = gpu["shapes"].torus_random(3000, seed=3)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((3000, 0)), k_neighbors=20)
+    pc.plant_kdtree(12)
+    assert pc.k_neighbors == 12 and pc.neighbor_indices.shape == (3000, 12)          # pct:71
