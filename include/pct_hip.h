@@ -50,6 +50,8 @@ typedef struct pct_timings {
     int64_t occupied_cells;
     int64_t ring_fallbacks;   /* queries that needed more than the 27-cell stencil      */
     int64_t lds_overflows;    /* cells whose stencil exceeded the LDS staging capacity  */
+    int64_t flushes;          /* wave-wide sort/merge passes of the sweep               */
+    int64_t candidate_steps;  /* 64-candidate distance steps of the sweep               */
     double cell_size;
 } pct_timings;
 
@@ -118,6 +120,9 @@ int pct_device_free(pct_ctx* ctx, void* dev_ptr);
 int pct_device_upload(pct_ctx* ctx, void* dev_dst, const void* host_src, int64_t bytes);
 int pct_device_download(pct_ctx* ctx, void* host_dst, const void* dev_src, int64_t bytes);
 int pct_synchronize(pct_ctx* ctx);
+/* Hardware self-test of the cross-lane primitives the sweep relies on
+ * (DPP / ds_swizzle lane exchanges); *failures == 0 on a healthy gfx950. */
+int pct_selftest(pct_ctx* ctx, int32_t* failures);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,7 @@ class Timings(C.Structure):
         ("knn_launches", C.c_int32), ("grid_iters", C.c_int32),
         ("cells", C.c_int64), ("occupied_cells", C.c_int64),
         ("ring_fallbacks", C.c_int64), ("lds_overflows", C.c_int64),
+        ("flushes", C.c_int64), ("candidate_steps", C.c_int64),
         ("cell_size", C.c_double),
     ]
 
@@ -71,6 +72,7 @@ SIGNATURES = {
     "pct_device_upload": (C.c_int, [_p, _p, _p, C.c_int64]),
     "pct_device_download": (C.c_int, [_p, _p, _p, C.c_int64]),
     "pct_synchronize": (C.c_int, [_p]),
+    "pct_selftest": (C.c_int, [_p, _i32p]),
 }
 
 _lib = None
@@ -243,6 +245,11 @@ class Handle:
     def device_download(self, ptr, host):
         assert host.flags["C_CONTIGUOUS"]
         self._check(self._lib.pct_device_download(self._h, host.ctypes.data_as(_p), _p(int(ptr)), host.nbytes))
+
+    def selftest(self):
+        n = C.c_int32(-1)
+        self._check(self._lib.pct_selftest(self._h, C.byref(n)))
+        return n.value
 
     def synchronize(self):
         self._check(self._lib.pct_synchronize(self._h))

@@ -202,11 +202,13 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
 }
 
 static int finish_knn_stats(pct_ctx* ctx) {
-    unsigned long long c[2] = {0, 0};
+    unsigned long long c[4] = {0, 0, 0, 0};
     PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.ring_fallbacks = (int64_t)c[0];
     ctx->tm.lds_overflows = (int64_t)c[1];
+    ctx->tm.flushes = (int64_t)c[2];
+    ctx->tm.candidate_steps = (int64_t)c[3];
     ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
     ctx->tm.knn_ms = ev_ms(ctx, 3, 4);
     return PCT_OK;
@@ -386,6 +388,17 @@ int pct_device_download(pct_ctx* ctx, void* host_dst, const void* dev_src, int64
 
 int pct_synchronize(pct_ctx* ctx) {
     PCT_TRY(begin_call(ctx));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_selftest(pct_ctx* ctx, int32_t* failures) {
+    PCT_TRY(begin_call(ctx));
+    if (!failures) return pct_fail(ctx, PCT_ERR_INVALID, "null output");
+    PCT_TRY(pct_reserve(ctx, &ctx->red, 64));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 64, ctx->stream));
+    PCT_TRY(pct_launch_selftest(ctx, (int*)ctx->red.p));
+    PCT_HIP(ctx, hipMemcpyAsync(failures, ctx->red.p, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCT_OK;
 }

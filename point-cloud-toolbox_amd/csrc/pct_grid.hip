@@ -54,17 +54,30 @@ __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ xyz, 
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
     }
+    __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
+    __shared__ int s_bad[kBlock / 64];
     for (int a = 0; a < 3; ++a) {
         mn[a] = wave_min(mn[a]);
         mx[a] = wave_max(mx[a]);
     }
     bad = __any(bad);
+    const int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
-        for (int a = 0; a < 3; ++a) {
-            atomicMin(&red[a], float_order(mn[a]));
-            atomicMax(&red[3 + a], float_order(mx[a]));
-        }
-        if (bad) atomicOr(&red[6], 1);
+        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
+        s_bad[w] = bad;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {      // one atomic per block and component (same-address atomics serialise)
+        const int a = threadIdx.x;
+        float lo = s_mn[0][a], hi = s_mx[0][a];
+        for (int i = 1; i < kBlock / 64; ++i) { lo = fminf(lo, s_mn[i][a]); hi = fmaxf(hi, s_mx[i][a]); }
+        atomicMin(&red[a], float_order(lo));
+        atomicMax(&red[3 + a], float_order(hi));
+    }
+    if (threadIdx.x == 3) {
+        int b = 0;
+        for (int i = 0; i < kBlock / 64; ++i) b |= s_bad[i];
+        if (b) atomicOr(&red[6], 1);
     }
 }
 
@@ -233,7 +246,7 @@ int pct_pack_points(pct_ctx* ctx, float* bbox /*6*/) {
     PCT_TRY(pct_reserve(ctx, &ctx->red, 64));
     int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
     PCT_HIP(ctx, hipMemcpyAsync(ctx->red.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_pack, dim3(grid_1d(n, kBlock, 2048)), dim3(kBlock), 0, ctx->stream,
+    hipLaunchKernelGGL(k_pack, dim3(grid_1d(n, kBlock * 4, 512)), dim3(kBlock), 0, ctx->stream,
                        (const float*)ctx->xyz.p, n, (float4*)ctx->pts4.p, (int*)ctx->red.p);
     PCT_HIP(ctx, hipGetLastError());
     int out[8];

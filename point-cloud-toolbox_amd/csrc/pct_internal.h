@@ -111,3 +111,4 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
                         const int64_t* d_query, int64_t rows, int32_t k,
                         float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
+int pct_launch_selftest(pct_ctx* ctx, int* d_fails);

@@ -9,13 +9,16 @@
 // by public index so the result does not depend on the cell order.
 //
 // Mapping to CDNA4: one 64-lane wave owns one occupied grid cell.  It stages the
-// 27-cell stencil once into LDS with coalesced 16 B/lane loads, then serves
-// every query of the cell from LDS: 64 candidates per step, one fp64 distance
-// per lane, a ballot against the running (k+1)-th distance, LDS compaction of
-// the survivors, and a wave-wide bitonic sort/merge (cross-lane shuffles, no
-// LDS traffic) whenever 64*R survivors are pending.  R = 1 holds k+1 <= 64,
-// R = 2 holds k+1 <= 128.  Queries whose (k+1)-th distance exceeds the stencil's
-// guaranteed radius widen the search shell by shell from global memory.
+// 27-cell stencil once into LDS (centre row first) with coalesced 16 B/lane
+// loads, then serves every query of the cell from LDS: 64 candidates per step,
+// one fp64 distance per lane, a ballot against the running (k+1)-th distance,
+// LDS compaction of the survivors, and a wave-wide bitonic sort/merge in
+// registers (DPP row operations for lane distances 1,2,4,8; ds_swizzle for 16;
+// ds_bpermute for 32) whenever 64*R survivors are pending.  R = 1 holds
+// k+1 <= 64, R = 2 holds k+1 <= 128.  A query is finished once its (k+1)-th
+// distance is inside the radius the searched cube guarantees; otherwise the cube
+// widens shell by shell from global memory.  The query loop has ONE candidate
+// step and ONE flush site so the kernel stays small enough for the I-cache.
 #include "pct_internal.h"
 
 #include <math.h>
@@ -39,7 +42,7 @@ struct KnnArgs {
     int* nbr_pos;
     float* nbr_dist;
     int* nbr_cnt;             // nullable
-    unsigned long long* counters;
+    unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -53,15 +56,38 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// value of lane (lane ^ S) -- S is a compile-time power of two
+template <int S>
+__device__ __forceinline__ int lane_xor(int v) {
+    if constexpr (S == 1) {
+        return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);             // quad_perm [1,0,3,2]
+    } else if constexpr (S == 2) {
+        return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xF, 0xF, true);             // quad_perm [2,3,0,1]
+    } else if constexpr (S == 4) {
+        int t = __builtin_amdgcn_update_dpp(v, v, 0x124, 0xF, 0xA, false);    // row_ror:4  -> banks 1,3 (lane bit2 set)
+        return __builtin_amdgcn_update_dpp(t, v, 0x12C, 0xF, 0x5, false);     // row_ror:12 -> banks 0,2
+    } else if constexpr (S == 8) {
+        return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);            // row_ror:8
+    } else if constexpr (S == 16) {
+        return __builtin_amdgcn_ds_swizzle(v, 0x401F);                        // bit mode: xor 16 inside 32 lanes
+    } else {
+        return __shfl_xor(v, S);                                              // ds_bpermute
+    }
+}
+
 __device__ __forceinline__ int pub_index(const float4* pts, int pos) { return __float_as_int(pts[pos].w); }
 
-// strict total order on (d2, public index); padding = (+inf, INT_MAX)
+// strict total order on (d2, public index); padding = (+inf, INT_MAX).
+// The public-index lookup only runs when some lane sees an exact fp64 tie.
 __device__ __forceinline__ bool key_less(double da, int pa, double db, int pb, const float4* pts) {
-    if (da < db) return true;
-    if (da > db || pa == pb) return false;
-    if (pa == INT_MAX) return false;
-    if (pb == INT_MAX) return true;
-    return pub_index(pts, pa) < pub_index(pts, pb);
+    const bool lt = da < db;
+    bool tie = (da == db) && (pa != pb) && (pa != INT_MAX) && (pb != INT_MAX);
+    bool tb = false;
+    if (__builtin_expect(__ballot(tie) != 0ull, 0)) {
+        if (tie) tb = pub_index(pts, pa) < pub_index(pts, pb);
+    }
+    // finite value vs padding with equal d2 cannot happen (padding is +inf); inf-vs-inf real elements do not exist
+    return lt || (tie && tb);
 }
 
 template <int R>
@@ -70,36 +96,35 @@ struct TopK {
     int p[R];
 };
 
-// One compare-exchange level of the bitonic network over 64*R elements, element
-// index i = lane + 64*slot.
-template <int R>
-__device__ __forceinline__ void bitonic_level(TopK<R>& t, int size, int stride, bool descending, const float4* pts) {
+// One compare-exchange level over 64*R elements, element index i = lane + 64*slot.
+template <int R, int STRIDE>
+__device__ __forceinline__ void bitonic_level(TopK<R>& t, int size, bool descending, const float4* pts) {
     const int lane = lane_id();
-    if (stride >= 64) {
-        const int ds = stride >> 6;
+    if constexpr (STRIDE >= 64) {
+        constexpr int ds = STRIDE >> 6;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            if ((r & ds) == 0) {
+            if ((r & ds) == 0 && (r | ds) < R) {
                 const int r2 = r | ds;
-                if (r2 < R) {
-                    const int i = lane + 64 * r;
-                    const bool asc = ((i & size) == 0) != descending;
-                    const bool hi_less = key_less(t.d[r2], t.p[r2], t.d[r], t.p[r], pts);
-                    if (hi_less == asc) {
-                        double td = t.d[r]; t.d[r] = t.d[r2]; t.d[r2] = td;
-                        int tp = t.p[r]; t.p[r] = t.p[r2]; t.p[r2] = tp;
-                    }
+                const int i = lane + 64 * r;
+                const bool asc = ((i & size) == 0) != descending;
+                const bool hi_less = key_less(t.d[r2], t.p[r2], t.d[r], t.p[r], pts);
+                if (hi_less == asc) {
+                    double td = t.d[r]; t.d[r] = t.d[r2]; t.d[r2] = td;
+                    int tp = t.p[r]; t.p[r] = t.p[r2]; t.p[r2] = tp;
                 }
             }
         }
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const double pd = __shfl_xor(t.d[r], stride);
-            const int pp = __shfl_xor(t.p[r], stride);
+            const int lo = lane_xor<STRIDE>(__double2loint(t.d[r]));
+            const int hi = lane_xor<STRIDE>(__double2hiint(t.d[r]));
+            const int pp = lane_xor<STRIDE>(t.p[r]);
+            const double pd = __hiloint2double(hi, lo);
             const int i = lane + 64 * r;
             const bool asc = ((i & size) == 0) != descending;
-            const bool keep_min = ((lane & stride) == 0) == asc;
+            const bool keep_min = ((lane & STRIDE) == 0) == asc;
             const bool partner_less = key_less(pd, pp, t.d[r], t.p[r], pts);
             if (keep_min == partner_less) {
                 t.d[r] = pd;
@@ -109,13 +134,16 @@ __device__ __forceinline__ void bitonic_level(TopK<R>& t, int size, int stride, 
     }
 }
 
-template <int R>
-__device__ __forceinline__ void bitonic_sort(TopK<R>& t, bool descending, const float4* pts) {
-#pragma unroll
-    for (int size = 2; size <= 64 * R; size <<= 1) {
-#pragma unroll
-        for (int stride = size >> 1; stride > 0; stride >>= 1) bitonic_level<R>(t, size, stride, descending, pts);
-    }
+template <int R, int STRIDE>
+__device__ __forceinline__ void bitonic_strides(TopK<R>& t, int size, bool descending, const float4* pts) {
+    bitonic_level<R, STRIDE>(t, size, descending, pts);
+    if constexpr (STRIDE > 1) bitonic_strides<R, STRIDE / 2>(t, size, descending, pts);
+}
+
+template <int R, int SIZE>
+__device__ __forceinline__ void bitonic_sort_from(TopK<R>& t, bool descending, const float4* pts) {
+    bitonic_strides<R, SIZE / 2>(t, SIZE, descending, pts);
+    if constexpr (SIZE < 64 * R) bitonic_sort_from<R, SIZE * 2>(t, descending, pts);
 }
 
 // best (ascending) <- smallest 64*R of best U batch; batch must be descending
@@ -128,8 +156,7 @@ __device__ __forceinline__ void bitonic_merge_min(TopK<R>& best, const TopK<R>& 
             best.p[r] = batch.p[r];
         }
     }
-#pragma unroll
-    for (int stride = 32 * R; stride > 0; stride >>= 1) bitonic_level<R>(best, 64 * R, stride, false, pts);
+    bitonic_strides<R, 32 * R>(best, 64 * R, false, pts);
 }
 
 // Per-wave running state for one query.
@@ -191,46 +218,30 @@ struct Sweep {
         if (lane < rest) { pend_d[lane] = md; pend_p[lane] = mp; }
         wave_lds_sync();
         npend = rest;
+        // first batch: ascending and adopted as-is; later batches: descending, then merged
+        bitonic_sort_from<R, 2>(b, !empty, pts);
         if (empty) {
-            bitonic_sort<R>(b, false, pts);
             best = b;
             empty = false;
         } else {
-            bitonic_sort<R>(b, true, pts);
             bitonic_merge_min<R>(best, b, pts);
         }
         refresh_tau();
     }
 
-    // one candidate per lane
+    // one candidate per lane; survivors are compacted into the pending buffer
     __device__ __forceinline__ void consider(float4 c, int pos, bool valid) {
         const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
         const double d2 = (dx * dx + dy * dy) + dz * dz;
-        const bool pass = valid && d2 < eps2 && key_less(d2, pos, tau_d, tau_p, pts);
+        const bool closer = key_less(d2, pos, tau_d, tau_p, pts);   // every lane takes part (wave ballot inside)
+        const bool pass = valid && d2 < eps2 && closer;
         const unsigned long long m = __ballot(pass);
-        if (m == 0) return;
         if (pass) {
             const int slot = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
             pend_d[slot] = d2;
             pend_p[slot] = pos;
         }
         npend += __popcll(m);
-        if (npend >= 64 * R) flush();
-    }
-
-    __device__ __forceinline__ void scan_global(int s, int e) {
-        const int lane = lane_id();
-        for (int base = s; base < e; base += 64) {
-            const int pos = base + lane;
-            const bool valid = pos < e;
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (valid) c = pts[pos];
-            consider(c, pos, valid);
-        }
-    }
-
-    __device__ __forceinline__ void finish() {
-        if (npend > 0 || empty) flush();
     }
 
     // rows: element i (1..k) -> output column i-1
@@ -254,47 +265,49 @@ struct Sweep {
     }
 };
 
+// (dz, dy) of the nine stencil rows, nearest first: the first batches then hold
+// the closest points and the (k+1)-th distance tightens early.
+__constant__ signed char kRowOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
+
 // ---------------------------------------------------------------------------
 // Grid sweep: wave = occupied cell
 // ---------------------------------------------------------------------------
 template <int R>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
-    __shared__ float4 s_cand[kWavesPerBlock][kStageCap];
-    __shared__ int s_pos[kWavesPerBlock][kStageCap];
+    __shared__ float4 s_cand[kWavesPerBlock][kStageCap];      // {x,y,z, sorted position}
     __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
     __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
 
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int64_t cell_slot = (int64_t)blockIdx.x * kWavesPerBlock + w;
     if (cell_slot >= a.n_occ) return;
 
     const pct_grid g = a.g;
-    const int cell = a.occ[cell_slot];
+    const int* __restrict__ cs = a.cell_start;
+    const int cell = __builtin_amdgcn_readfirstlane(a.occ[cell_slot]);
     const int cx = cell % g.nx;
     const int cy = (cell / g.nx) % g.ny;
     const int cz = cell / (g.nx * g.ny);
-    const int qs = a.cell_start[cell], qe = a.cell_start[cell + 1];
+    const int qs = cs[cell], qe = cs[cell + 1];
 
     // ---- stage the 27-cell stencil (9 x-runs of <= 3 consecutive cells) ----
     float4* cand = s_cand[w];
-    int* cpos = s_pos[w];
     int m = 0;
-    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= g.nz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = cy + dy;
-            if (y < 0 || y >= g.ny) continue;
+    {
+        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
+        for (int t = 0; t < 9; ++t) {
+            const int z = cz + kRowOrder[t][0], y = cy + kRowOrder[t][1];
+            if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
             const int row = (z * g.ny + y) * g.nx;
-            const int s = a.cell_start[row + x0], e = a.cell_start[row + x1 + 1];
+            const int s = cs[row + x0], e = cs[row + x1 + 1];
             for (int base = s; base < e; base += 64) {
                 const int pos = base + lane;
                 const int slot = m + (pos - s);
                 if (pos < e && slot < kStageCap) {
-                    cand[slot] = a.pts[pos];
-                    cpos[slot] = pos;
+                    float4 c = a.pts[pos];
+                    c.w = __int_as_float(pos);
+                    cand[slot] = c;
                 }
             }
             m += e - s;
@@ -302,7 +315,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
     }
     wave_lds_sync();
     const bool staged = m <= kStageCap;
-    if (!staged && lane == 0) atomicAdd(&a.counters[1], 1ull);
 
     Sweep<R> sw;
     sw.k = a.k;
@@ -311,12 +323,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
     sw.pend_d = s_pend_d[w];
     sw.pend_p = s_pend_p[w];
 
-    const double cell_len = g.cell * (1.0 - 1e-6);
-    unsigned long long fallbacks = 0;
+    unsigned long long n_fallback = 0, n_flush = 0, n_step = 0;
 
     for (int q = qs; q < qe; ++q) {
         const float4 qp = a.pts[q];
-        const int pub = __float_as_int(qp.w);
+        const int pub = __builtin_amdgcn_readfirstlane(__float_as_int(qp.w));
         if (pub < a.q_begin || pub >= a.q_end) continue;
         if (a.ptsd) {
             const double4 qd = a.ptsd[q];
@@ -325,63 +336,102 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
             sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
         }
         sw.reset();
+        // position of the query inside its cell, in cell units (fp64)
+        const double gx = (sw.qx - g.ox) * g.inv_cell - cx;
+        const double gy = (sw.qy - g.oy) * g.inv_cell - cy;
+        const double gz = (sw.qz - g.oz) * g.inv_cell - cz;
 
-        if (staged) {
-            for (int base = 0; base < m; base += 64) {
-                const int slot = base + lane;
-                const bool valid = slot < m;
-                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-                int pos = 0;
-                if (valid) { c = cand[slot]; pos = cpos[slot]; }
-                sw.consider(c, pos, valid);
-            }
-        } else {
-            for (int dz = -1; dz <= 1; ++dz) {
-                const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-                for (int dy = -1; dy <= 1; ++dy) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
-                    const int row = (z * g.ny + y) * g.nx;
-                    sw.scan_global(a.cell_start[row + x0], a.cell_start[row + x1 + 1]);
-                }
-            }
-        }
-        sw.finish();
-
-        // ---- widen shell by shell until the guarantee radius covers the answer
+        // ---- candidate iterator: ring 1 from LDS (or global when it overflowed), rings >= 2 from global shells
         int ring = 1;
-        while (true) {
-            const double need = fmin(sw.tau_d, sw.eps2);
-            const double rr = ring * cell_len;
-            if (need <= rr * rr) break;
-            const bool covered = cx - ring <= 0 && cx + ring >= g.nx - 1 && cy - ring <= 0 && cy + ring >= g.ny - 1 &&
-                                 cz - ring <= 0 && cz + ring >= g.nz - 1;
-            if (covered) break;
-            ++ring;
-            if (ring == 2) ++fallbacks;
-            const int xa = cx - ring, xb = cx + ring;
-            const int xa_c = max(xa, 0), xb_c = min(xb, g.nx - 1);
-            for (int dz = -ring; dz <= ring; ++dz) {
-                const int z = cz + dz;
-                if (z < 0 || z >= g.nz) continue;
-                for (int dy = -ring; dy <= ring; ++dy) {
-                    const int y = cy + dy;
-                    if (y < 0 || y >= g.ny) continue;
-                    const int row = (z * g.ny + y) * g.nx;
-                    if (dz == -ring || dz == ring || dy == -ring || dy == ring) {
-                        sw.scan_global(a.cell_start[row + xa_c], a.cell_start[row + xb_c + 1]);
-                    } else {
-                        if (xa >= 0) sw.scan_global(a.cell_start[row + xa], a.cell_start[row + xa + 1]);
-                        if (xb < g.nx) sw.scan_global(a.cell_start[row + xb], a.cell_start[row + xb + 1]);
+        bool from_lds = staged;
+        bool full_cube = !staged;      // ring 1 from global: every row is a full x-run
+        int base = 0;
+        int it_dz = -1, it_dy = -1, it_part = 0, seg_pos = 0, seg_end = 0;
+
+        for (;;) {
+            bool have = false, valid = false;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            int pos = 0;
+            if (from_lds) {
+                if (base < m) {
+                    const int slot = base + lane;
+                    valid = slot < m;
+                    if (valid) { c = cand[slot]; pos = __float_as_int(c.w); }
+                    base += 64;
+                    have = true;
+                }
+            } else {
+                // advance to the next non-empty x-run of the current ring
+                while (seg_pos >= seg_end && it_dz <= ring) {
+                    const int z = cz + it_dz, y = cy + it_dy;
+                    const bool face = full_cube || it_dz == -ring || it_dz == ring || it_dy == -ring || it_dy == ring;
+                    int s = 0, e = 0;
+                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                        const int row = (z * g.ny + y) * g.nx;
+                        if (face) {
+                            s = cs[row + max(cx - ring, 0)];
+                            e = cs[row + min(cx + ring, g.nx - 1) + 1];
+                        } else if (it_part == 0) {
+                            if (cx - ring >= 0) { s = cs[row + cx - ring]; e = cs[row + cx - ring + 1]; }
+                        } else {
+                            if (cx + ring < g.nx) { s = cs[row + cx + ring]; e = cs[row + cx + ring + 1]; }
+                        }
                     }
+                    if (face || it_part == 1) {
+                        it_part = 0;
+                        if (++it_dy > ring) { it_dy = -ring; ++it_dz; }
+                    } else {
+                        it_part = 1;
+                    }
+                    seg_pos = s;
+                    seg_end = e;
+                }
+                if (seg_pos < seg_end) {
+                    pos = seg_pos + lane;
+                    valid = pos < seg_end;
+                    if (valid) c = a.pts[pos];
+                    seg_pos += 64;
+                    have = true;
                 }
             }
-            sw.finish();
+            if (have) {
+                sw.consider(c, pos, valid);
+                ++n_step;
+                if (sw.npend < 64 * R) continue;
+            }
+            if (sw.npend > 0 || sw.empty) {     // the ONE flush site
+                sw.flush();
+                ++n_flush;
+            }
+            if (have) continue;
+
+            // ring exhausted: is every point closer than the (k+1)-th best inside the searched cube?
+            const double inf = INFINITY;
+            double gmin = inf;
+            gmin = fmin(gmin, cx - ring <= 0 ? inf : gx + ring);
+            gmin = fmin(gmin, cx + ring >= g.nx - 1 ? inf : (1.0 - gx) + ring);
+            gmin = fmin(gmin, cy - ring <= 0 ? inf : gy + ring);
+            gmin = fmin(gmin, cy + ring >= g.ny - 1 ? inf : (1.0 - gy) + ring);
+            gmin = fmin(gmin, cz - ring <= 0 ? inf : gz + ring);
+            gmin = fmin(gmin, cz + ring >= g.nz - 1 ? inf : (1.0 - gz) + ring);
+            const double rr = gmin * g.cell * (1.0 - 1e-6);
+            const double need = fmin(sw.tau_d, sw.eps2);
+            if (need <= rr * rr) break;
+            ++ring;
+            if (ring == 2) ++n_fallback;
+            from_lds = false;
+            full_cube = false;
+            it_dz = -ring; it_dy = -ring; it_part = 0;
+            seg_pos = seg_end = 0;
         }
         sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
     }
-    if (fallbacks && lane == 0) atomicAdd(&a.counters[0], fallbacks);
+    if (lane == 0) {
+        if (n_fallback) atomicAdd(&a.counters[0], n_fallback);
+        if (!staged) atomicAdd(&a.counters[1], 1ull);
+        atomicAdd(&a.counters[2], n_flush);
+        atomicAdd(&a.counters[3], n_step);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -393,7 +443,8 @@ template <int R>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_brute(KnnArgs a) {
     __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
     __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
     const int64_t q = (int64_t)a.q_begin + (int64_t)blockIdx.x * kWavesPerBlock + w;
     if (q >= a.q_end) return;
 
@@ -411,8 +462,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_brute(KnnArgs a) {
         sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
     }
     sw.reset();
-    sw.scan_global(0, (int)a.n);
-    sw.finish();
+    const int n = (int)a.n;
+    for (int base = 0;; base += 64) {
+        const bool have = base < n;
+        if (have) {
+            const int pos = base + lane;
+            const bool valid = pos < n;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) c = a.pts[pos];
+            sw.consider(c, pos, valid);
+            if (sw.npend < 64 * R) continue;
+        }
+        if (sw.npend > 0 || sw.empty) sw.flush();
+        if (!have) break;
+    }
     sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
 }
 
@@ -433,6 +496,20 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
     if (idx_out) idx_out[o] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
     if (dist_out) dist_out[o] = nbr_dist[row * k + j];
     if (cnt_out && j == 0) cnt_out[pub - begin] = nbr_cnt ? nbr_cnt[row] : k;
+}
+
+// lane_xor<S>() against the generic shuffle, every S (hardware self-test)
+__global__ __launch_bounds__(64) void k_selftest(int* fails) {
+    const int lane = lane_id();
+    const int v = lane * 7919 + 13;
+    int bad = 0;
+    bad += lane_xor<1>(v) != __shfl_xor(v, 1);
+    bad += lane_xor<2>(v) != __shfl_xor(v, 2);
+    bad += lane_xor<4>(v) != __shfl_xor(v, 4);
+    bad += lane_xor<8>(v) != __shfl_xor(v, 8);
+    bad += lane_xor<16>(v) != __shfl_xor(v, 16);
+    bad += lane_xor<32>(v) != __shfl_xor(v, 32);
+    if (bad) atomicAdd(fails, bad);
 }
 
 KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
@@ -505,6 +582,12 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream, pts, (const int*)ctx->nbr_pos.p,
                        (const float*)ctx->nbr_dist.p, ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n,
                        ctx->k, begin, end, d_idx, d_dist, d_cnt);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_launch_selftest(pct_ctx* ctx, int* d_fails) {
+    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, ctx->stream, d_fails);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

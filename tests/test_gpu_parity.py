@@ -31,6 +31,12 @@ def run_cloud(gpu, pts, k, algorithm="auto", eps=None):
     return pc, K, H
 
 
+def test_cross_lane_primitives(gpu):
+    h = gpu["capi"].Handle(0)
+    assert h.selftest() == 0
+    h.close()
+
+
 # ------------------------------------------------------------------ goldens
 @pytest.mark.parametrize("name", ["g1_sphere2k_k30.npz", "g2_torus4k_k50.npz", "g3_egg4k_k50.npz"])
 @pytest.mark.parametrize("algorithm", ["brute", "grid"])
@@ -273,10 +279,10 @@ def test_curvatures_from_coefficients(gpu, golden):
 def test_error_conventions(gpu):
     PC = gpu["PointCloud"]
     pts = gpu["shapes"].torus_random(500, seed=1)
-    bad = pts.copy()
-    bad[17, 2] = np.nan
+    nan_pc = PC(points=pts.copy(), normals=np.zeros((500, 0)))
+    nan_pc.points[17, 2] = np.nan       # (a NaN at construction already dies in the ctor's norm, pct:46)
     with pytest.raises(ValueError, match="Non-finite values in input points"):      # pct:274
-        PC(points=bad, normals=np.zeros((500, 0))).plant_kdtree(10)
+        nan_pc.plant_kdtree(10)
     with pytest.raises(IndexError):                                                 # k+1 > N (pct:640)
         PC(points=pts[:20], normals=np.zeros((20, 0))).plant_kdtree(20)
     pc = PC(points=pts, normals=np.zeros((500, 0)))
