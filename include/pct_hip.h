@@ -33,7 +33,8 @@ enum pct_status {
 enum pct_knn_algo {
     PCT_KNN_AUTO = 0,
     PCT_KNN_BRUTE = 1,        /* exhaustive wave-per-query sweep                        */
-    PCT_KNN_GRID = 2          /* uniform cell list, LDS-staged 27-cell stencil          */
+    PCT_KNN_GRID = 2,         /* uniform cell list, LDS-staged 27-cell stencil          */
+    PCT_KNN_GRID_EXACT = 3    /* same cell list, every query through the exact sweep    */
 };
 
 /* Per-stage device times of the most recent call, hipEvent milliseconds. */
@@ -47,11 +48,12 @@ typedef struct pct_timings {
     int32_t knn_launches;
     int32_t grid_iters;       /* cell-size refinement passes                            */
     int64_t cells;            /* grid cells                                             */
-    int64_t occupied_cells;
+    int64_t occupied_cells;   /* work items of the sweep (cells split into query chunks) */
     int64_t ring_fallbacks;   /* queries that needed more than the 27-cell stencil      */
     int64_t lds_overflows;    /* cells whose stencil exceeded the LDS staging capacity  */
     int64_t flushes;          /* wave-wide sort/merge passes of the sweep               */
     int64_t candidate_steps;  /* 64-candidate distance steps of the sweep               */
+    int64_t redone_queries;   /* queries re-done by the exact sweep (float-key collisions) */
     double cell_size;
 } pct_timings;
 
@@ -77,6 +79,9 @@ int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end);
 /* Cell-occupancy target of the grid search as a multiple of (k+1); <= 0 keeps
  * the default. */
 int pct_set_grid_param(pct_ctx* ctx, double occupancy_factor);
+/* Sweep statistics in pct_timings (ring_fallbacks ... redone_queries); off by default
+ * because the counters cost same-address atomics. */
+int pct_set_stats(pct_ctx* ctx, int32_t enable);
 
 /* ---- plant_kdtree(k) (pct:69-89) ---------------------------------------- */
 /* k nearest neighbours of every owned point, self dropped, rows ascending.

@@ -23,7 +23,7 @@ PCT_ERR_K_TOO_LARGE = 5
 PCT_ERR_OOM = 6
 PCT_ERR_NO_NEIGHBORS = 7
 
-KNN_AUTO, KNN_BRUTE, KNN_GRID = 0, 1, 2
+KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT = 0, 1, 2, 3
 
 
 class Timings(C.Structure):
@@ -33,7 +33,7 @@ class Timings(C.Structure):
         ("knn_launches", C.c_int32), ("grid_iters", C.c_int32),
         ("cells", C.c_int64), ("occupied_cells", C.c_int64),
         ("ring_fallbacks", C.c_int64), ("lds_overflows", C.c_int64),
-        ("flushes", C.c_int64), ("candidate_steps", C.c_int64),
+        ("flushes", C.c_int64), ("candidate_steps", C.c_int64), ("redone_queries", C.c_int64),
         ("cell_size", C.c_double),
     ]
 
@@ -59,6 +59,7 @@ SIGNATURES = {
     "pct_set_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
     "pct_set_query_range": (C.c_int, [_p, C.c_int64, C.c_int64]),
     "pct_set_grid_param": (C.c_int, [_p, C.c_double]),
+    "pct_set_stats": (C.c_int, [_p, C.c_int32]),
     "pct_knn": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
     "pct_get_neighbors": (C.c_int, [_p, C.c_int64, C.c_int64, _i32p, _f32p, _i32p]),
     "pct_fit": (C.c_int, [_p]),
@@ -170,6 +171,9 @@ class Handle:
 
     def set_query_range(self, begin, end):
         self._check(self._lib.pct_set_query_range(self._h, int(begin), int(end)))
+
+    def set_stats(self, enable=True):
+        self._check(self._lib.pct_set_stats(self._h, int(bool(enable))))
 
     def set_grid_param(self, occupancy_factor):
         self._check(self._lib.pct_set_grid_param(self._h, float(occupancy_factor)))

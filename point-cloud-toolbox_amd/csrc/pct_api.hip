@@ -85,7 +85,7 @@ void pct_destroy(pct_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
-                      &ctx->scan_tmp, &ctx->occ, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
+                      &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
                       &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
     for (pct_buf* b : all) release(b);
@@ -169,6 +169,12 @@ int pct_set_grid_param(pct_ctx* ctx, double occupancy_factor) {
     return PCT_OK;
 }
 
+int pct_set_stats(pct_ctx* ctx, int32_t enable) {
+    PCT_TRY(begin_call(ctx));
+    ctx->collect_stats = enable != 0;
+    return PCT_OK;
+}
+
 // neighbour sweep without timing bookkeeping; events 2..4 bracket grid / sweep
 static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
@@ -176,12 +182,13 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
     if (!(eps >= 0) || isinf(eps)) eps = 0;
     if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
-    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE) return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
+    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT) return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
     ctx->knn_valid = ctx->fit_valid = false;
     ctx->k = k;
     ctx->eps = eps;
     PCT_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-    if (algo == PCT_KNN_GRID) {
+    const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
+    if (grid) {
         PCT_TRY(pct_build_grid(ctx, k, eps));
     } else {
         float bbox[6];
@@ -191,8 +198,8 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         ctx->tm.cell_size = 0;
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-    if (algo == PCT_KNN_GRID)
-        PCT_TRY(pct_launch_knn_grid(ctx, k, eps));
+    if (grid)
+        PCT_TRY(pct_launch_knn_grid(ctx, k, eps, algo == PCT_KNN_GRID_EXACT));
     else
         PCT_TRY(pct_launch_knn_brute(ctx, k, eps));
     PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
@@ -202,13 +209,14 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
 }
 
 static int finish_knn_stats(pct_ctx* ctx) {
-    unsigned long long c[4] = {0, 0, 0, 0};
+    unsigned long long c[5] = {0, 0, 0, 0, 0};
     PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.ring_fallbacks = (int64_t)c[0];
     ctx->tm.lds_overflows = (int64_t)c[1];
     ctx->tm.flushes = (int64_t)c[2];
     ctx->tm.candidate_steps = (int64_t)c[3];
+    ctx->tm.redone_queries = (int64_t)c[4];
     ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
     ctx->tm.knn_ms = ev_ms(ctx, 3, 4);
     return PCT_OK;

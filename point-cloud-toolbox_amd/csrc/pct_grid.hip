@@ -121,7 +121,7 @@ __global__ __launch_bounds__(kBlock) void k_occupancy(const int* __restrict__ ce
     if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
 }
 
-// ---- dual exclusive scan: counts -> starts, (count>0) -> occupied rank ------
+// ---- dual exclusive scan: counts -> starts, ceil(count/items_q) -> work-item rank ------
 constexpr int kScanItems = 8;                    // per thread
 constexpr int kScanTile = kBlock * kScanItems;   // 2048 cells per block
 
@@ -139,7 +139,7 @@ __device__ __forceinline__ int2 block_reduce2(int2 v, int2* sh) {
     return t;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cnt, int64_t ncell, int2* __restrict__ tmp) {
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cnt, int64_t ncell, int items_q, int2* __restrict__ tmp) {
     __shared__ int2 sh[kBlock / 64];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int2 v = make_int2(0, 0);
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cn
         int64_t c = base + j;
         int x = c < ncell ? cnt[c] : 0;
         v.x += x;
-        v.y += x > 0;
+        v.y += (x + items_q - 1) / items_q;
     }
     int2 t = block_reduce2(v, sh);
     if (threadIdx.x == 0) tmp[blockIdx.x] = t;
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int2* __restrict__ tmp, int
     if (threadIdx.x == 0) tmp[nblk] = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, int64_t ncell, const int2* __restrict__ tmp,
-                                                       int* __restrict__ occ) {
+__global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, int64_t ncell, int items_q,
+                                                       const int2* __restrict__ tmp, int2* __restrict__ items) {
     __shared__ int2 sh[kBlock];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int x[kScanItems];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, in
         int64_t c = base + j;
         x[j] = c < ncell ? cnt[c] : 0;
         v.x += x[j];
-        v.y += x[j] > 0;
+        v.y += (x[j] + items_q - 1) / items_q;
     }
     sh[threadIdx.x] = v;
     __syncthreads();
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, in
         int64_t c = base + j;
         if (c < ncell) {
             cnt[c] = s;
-            if (x[j] > 0) occ[r++] = (int)c;
+            for (int ch = 0; ch * items_q < x[j]; ++ch) items[r++] = make_int2((int)c, ch);
             s += x[j];
         }
     }
@@ -354,12 +354,14 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // exclusive scan + ordered occupied-cell list
     const int nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int2)));
-    PCT_TRY(pct_reserve(ctx, &ctx->occ, (size_t)(n < g.ncell ? n : g.ncell) * sizeof(int)));
+    const int items_q = ctx->items_q > 0 ? ctx->items_q : 12;
+    ctx->items_q = items_q;
+    PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n < g.ncell ? n : g.ncell) + (size_t)n / items_q + 16) * sizeof(int2)));
     hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                       (const int*)ctx->cell_cnt.p, g.ncell, (int2*)ctx->scan_tmp.p);
+                       (const int*)ctx->cell_cnt.p, g.ncell, items_q, (int2*)ctx->scan_tmp.p);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int2*)ctx->scan_tmp.p, nblk);
     hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                       (int*)ctx->cell_cnt.p, g.ncell, (const int2*)ctx->scan_tmp.p, (int*)ctx->occ.p);
+                       (int*)ctx->cell_cnt.p, g.ncell, items_q, (const int2*)ctx->scan_tmp.p, (int2*)ctx->occ.p);
     PCT_HIP(ctx, hipGetLastError());
     int2 tot;
     PCT_HIP(ctx, hipMemcpyAsync(&tot, (int2*)ctx->scan_tmp.p + nblk, sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
@@ -377,6 +379,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tot.x != n) return pct_fail(ctx, PCT_ERR_INVALID, "cell scan total %d != n %lld", tot.x, (long long)n);
+    ctx->n_items = tot.y;
     ctx->n_occ = tot.y;
     ctx->tm.occupied_cells = tot.y;
     ctx->grid_valid = true;

@@ -38,6 +38,7 @@ struct pct_ctx {
     int64_t q_begin = 0, q_end = 0;
     bool has_f64 = false;
     double occupancy_factor = 0.0; // 0 = default
+    bool collect_stats = false;    // sweep statistics (costly same-address atomics)
 
     // coordinates
     pct_buf xyz;        // float  (n,3) public order
@@ -49,7 +50,10 @@ struct pct_ctx {
     pct_buf cell_cnt;   // int32 (ncell+1) counts -> exclusive starts
     pct_buf cell_fill;  // int32 (ncell) scatter cursors
     pct_buf scan_tmp;   // block sums
-    pct_buf occ;        // int32 (n_occ) occupied cell ids
+    pct_buf occ;        // int2 (n_items) work items {cell id, chunk of items_q queries}
+    pct_buf redo;       // int32 (n) queries the fast sweep handed to the exact sweep
+    int64_t n_items = 0;
+    int32_t items_q = 12;
     pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
     pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
     pct_buf red;        // small reduction scratch
@@ -101,7 +105,7 @@ int pct_pack_points(pct_ctx* ctx, float* bbox6);
 int pct_pack_points_f64(pct_ctx* ctx, const double* d_xyz64);
 int pct_build_grid(pct_ctx* ctx, int32_t k, double eps);
 // neighbour sweeps (pct_knn.hip)
-int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps);
+int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only);
 int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);

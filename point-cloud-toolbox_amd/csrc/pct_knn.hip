@@ -13,8 +13,8 @@
 // loads, then serves every query of the cell from LDS: 64 candidates per step,
 // one fp64 distance per lane, a ballot against the running (k+1)-th distance,
 // LDS compaction of the survivors, and a wave-wide bitonic sort/merge in
-// registers (DPP row operations for lane distances 1,2,4,8; ds_swizzle for 16;
-// ds_bpermute for 32) whenever 64*R survivors are pending.  R = 1 holds
+// registers (DPP row operations for lane distances 1,2,4,8; v_permlane16_swap /
+// v_permlane32_swap for 16 and 32: no LDS round trip anywhere in the network) whenever 64*R survivors are pending.  R = 1 holds
 // k+1 <= 64, R = 2 holds k+1 <= 128.  A query is finished once its (k+1)-th
 // distance is inside the radius the searched cube guarantees; otherwise the cube
 // widens shell by shell from global memory.  The query loop has ONE candidate
@@ -42,7 +42,8 @@ struct KnnArgs {
     int* nbr_pos;
     float* nbr_dist;
     int* nbr_cnt;             // nullable
-    unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps
+    int stats;                // collect the counters below (off by default)
+    unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -69,9 +70,13 @@ __device__ __forceinline__ int lane_xor(int v) {
     } else if constexpr (S == 8) {
         return __builtin_amdgcn_mov_dpp(v, 0x128, 0xF, 0xF, true);            // row_ror:8
     } else if constexpr (S == 16) {
-        return __builtin_amdgcn_ds_swizzle(v, 0x401F);                        // bit mode: xor 16 inside 32 lanes
+        // v_permlane16_swap: odd rows of the first operand <-> even rows of the second (VALU, no LDS round trip)
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((threadIdx.x & 16) ? r[0] : r[1]);
     } else {
-        return __shfl_xor(v, S);                                              // ds_bpermute
+        // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second
+        const auto r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+        return (int)((threadIdx.x & 32) ? r[0] : r[1]);
     }
 }
 
@@ -269,52 +274,86 @@ struct Sweep {
 // the closest points and the (k+1)-th distance tightens early.
 __constant__ signed char kRowOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
 
-// ---------------------------------------------------------------------------
-// Grid sweep: wave = occupied cell
-// ---------------------------------------------------------------------------
-template <int R>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
-    __shared__ float4 s_cand[kWavesPerBlock][kStageCap];      // {x,y,z, sorted position}
-    __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
-    __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
-
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = lane_id();
-    const int64_t cell_slot = (int64_t)blockIdx.x * kWavesPerBlock + w;
-    if (cell_slot >= a.n_occ) return;
-
-    const pct_grid g = a.g;
-    const int* __restrict__ cs = a.cell_start;
-    const int cell = __builtin_amdgcn_readfirstlane(a.occ[cell_slot]);
-    const int cx = cell % g.nx;
-    const int cy = (cell / g.nx) % g.ny;
-    const int cz = cell / (g.nx * g.ny);
-    const int qs = cs[cell], qe = cs[cell + 1];
-
-    // ---- stage the 27-cell stencil (9 x-runs of <= 3 consecutive cells) ----
-    float4* cand = s_cand[w];
-    int m = 0;
-    {
-        const int x0 = max(cx - 1, 0), x1 = min(cx + 1, g.nx - 1);
-        for (int t = 0; t < 9; ++t) {
-            const int z = cz + kRowOrder[t][0], y = cy + kRowOrder[t][1];
-            if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
-            const int row = (z * g.ny + y) * g.nx;
-            const int s = cs[row + x0], e = cs[row + x1 + 1];
-            for (int base = s; base < e; base += 64) {
-                const int pos = base + lane;
-                const int slot = m + (pos - s);
-                if (pos < e && slot < kStageCap) {
-                    float4 c = a.pts[pos];
-                    c.w = __int_as_float(pos);
-                    cand[slot] = c;
+// Wave-uniform iterator over the x-runs of the cube shell of radius `ring`
+// around cell (cx,cy,cz); ring 1 with full == true enumerates the whole 27-cell cube.
+struct ShellIter {
+    int ring, dz, dy, part, pos, end;
+    bool full;
+    __device__ __forceinline__ void start(int r, bool whole_cube) {
+        ring = r; dz = -r; dy = -r; part = 0; pos = 0; end = 0; full = whole_cube;
+    }
+    // next 64-candidate step: returns false when the shell is exhausted
+    __device__ __forceinline__ bool next(const pct_grid& g, const int* __restrict__ cs, int cx, int cy, int cz, int& base, int& lim) {
+        while (pos >= end && dz <= ring) {
+            const int z = cz + dz, y = cy + dy;
+            const bool face = full || dz == -ring || dz == ring || dy == -ring || dy == ring;
+            int s = 0, e = 0;
+            if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                const int row = (z * g.ny + y) * g.nx;
+                if (face) {
+                    s = cs[row + max(cx - ring, 0)];
+                    e = cs[row + min(cx + ring, g.nx - 1) + 1];
+                } else if (part == 0) {
+                    if (cx - ring >= 0) { s = cs[row + cx - ring]; e = cs[row + cx - ring + 1]; }
+                } else {
+                    if (cx + ring < g.nx) { s = cs[row + cx + ring]; e = cs[row + cx + ring + 1]; }
                 }
             }
-            m += e - s;
+            if (face || part == 1) {
+                part = 0;
+                if (++dy > ring) { dy = -ring; ++dz; }
+            } else {
+                part = 1;
+            }
+            pos = s;
+            end = e;
         }
+        if (pos >= end) return false;
+        base = pos;
+        lim = end;
+        pos += 64;
+        return true;
     }
-    wave_lds_sync();
-    const bool staged = m <= kStageCap;
+};
+
+// squared radius (cell units folded in) inside which the cube of radius `ring`
+// around the query's cell is known to contain every point; +inf once the cube
+// covers the grid.  gx,gy,gz = position of the query inside its cell in cell units.
+__device__ __forceinline__ double guaranteed_r2(const pct_grid& g, int cx, int cy, int cz, double gx, double gy, double gz, int ring) {
+    const double inf = INFINITY;
+    double gmin = inf;
+    gmin = fmin(gmin, cx - ring <= 0 ? inf : gx + ring);
+    gmin = fmin(gmin, cx + ring >= g.nx - 1 ? inf : (1.0 - gx) + ring);
+    gmin = fmin(gmin, cy - ring <= 0 ? inf : gy + ring);
+    gmin = fmin(gmin, cy + ring >= g.ny - 1 ? inf : (1.0 - gy) + ring);
+    gmin = fmin(gmin, cz - ring <= 0 ? inf : gz + ring);
+    gmin = fmin(gmin, cz + ring >= g.nz - 1 ? inf : (1.0 - gz) + ring);
+    const double rr = gmin * g.cell * (1.0 - 1e-6);
+    return rr * rr;
+}
+
+__device__ __forceinline__ int cell_coord_d(double x, double o, double inv, int n) {
+    int c = (int)floor((x - o) * inv);
+    return min(max(c, 0), n - 1);
+}
+
+// ---------------------------------------------------------------------------
+// Exact sweep, wave = query, candidates from global memory cube by cube.
+// Runs (a) the queries the fast kernel flagged as ambiguous (list != null) and
+// (b) every owned query when the exact path is requested for testing.
+// Comparisons are on (fp64 d2, public index), so ties are resolved exactly.
+// ---------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, const int* __restrict__ list,
+                                                                   const int* __restrict__ list_count) {
+    __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
+    __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const pct_grid g = a.g;
+    const int* __restrict__ cs = a.cell_start;
+    const int64_t total = list ? (int64_t)*list_count : a.n;
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
 
     Sweep<R> sw;
     sw.k = a.k;
@@ -323,12 +362,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
     sw.pend_d = s_pend_d[w];
     sw.pend_p = s_pend_p[w];
 
-    unsigned long long n_fallback = 0, n_flush = 0, n_step = 0;
-
-    for (int q = qs; q < qe; ++q) {
+    for (int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w; item < total; item += nwaves) {
+        const int q = list ? list[item] : (int)item;
         const float4 qp = a.pts[q];
         const int pub = __builtin_amdgcn_readfirstlane(__float_as_int(qp.w));
         if (pub < a.q_begin || pub >= a.q_end) continue;
+        // the query's cell comes from its float32 (tree) coordinates, as in the build
+        const int cx = __builtin_amdgcn_readfirstlane(cell_coord_d((double)qp.x, g.ox, g.inv_cell, g.nx));
+        const int cy = __builtin_amdgcn_readfirstlane(cell_coord_d((double)qp.y, g.oy, g.inv_cell, g.ny));
+        const int cz = __builtin_amdgcn_readfirstlane(cell_coord_d((double)qp.z, g.oz, g.inv_cell, g.nz));
         if (a.ptsd) {
             const double4 qd = a.ptsd[q];
             sw.qx = qd.x; sw.qy = qd.y; sw.qz = qd.z;
@@ -336,101 +378,376 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_grid(KnnArgs a) {
             sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
         }
         sw.reset();
-        // position of the query inside its cell, in cell units (fp64)
         const double gx = (sw.qx - g.ox) * g.inv_cell - cx;
         const double gy = (sw.qy - g.oy) * g.inv_cell - cy;
         const double gz = (sw.qz - g.oz) * g.inv_cell - cz;
+        ShellIter it;
+        it.start(1, true);
+        for (;;) {
+            int base = 0, lim = 0;
+            const bool have = it.next(g, cs, cx, cy, cz, base, lim);
+            if (have) {
+                const int pos = base + lane;
+                const bool valid = pos < lim;
+                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (valid) c = a.pts[pos];
+                sw.consider(c, pos, valid);
+                if (sw.npend < 64 * R) continue;
+            }
+            if (sw.npend > 0 || sw.empty) sw.flush();
+            if (have) continue;
+            if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, it.ring)) break;
+            it.start(it.ring + 1, false);
+        }
+        sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+    }
+}
 
-        // ---- candidate iterator: ring 1 from LDS (or global when it overflowed), rings >= 2 from global shells
-        int ring = 1;
+// ---------------------------------------------------------------------------
+// Fast sweep: wave = work item (one cell, <= items_q consecutive queries).
+//
+// Elements of the wave-wide network are single 64-bit integers
+//     (float32 bits of the fp64 squared distance) << 32 | payload
+// payload = LDS slot of a staged candidate, or 0x80000000 | sorted position of
+// a candidate streamed from global.  float(d2) is a monotone map of the exact
+// fp64 value, so wherever two float keys differ the order is the exact order.
+// Every situation in which a float key collision could influence the k+1
+// smallest (a rejected or dropped candidate sharing the threshold's float key,
+// equal neighbours in the final list) raises a flag; flagged queries are
+// appended to the redo list and re-done by k_knn_exact.  Unflagged results are
+// therefore bit-identical to the exact path: the stored distance is recomputed
+// in fp64 from the coordinates.  One compare-exchange level costs two DPP moves,
+// one 64-bit integer compare, one scalar mask op and two selects.
+// ---------------------------------------------------------------------------
+typedef unsigned long long u64;
+constexpr u64 kPadKey = ~0ull;
+
+template <int S>
+__device__ __forceinline__ u64 lane_xor64(u64 v) {
+    const unsigned lo = (unsigned)lane_xor<S>((int)(unsigned)v);
+    const unsigned hi = (unsigned)lane_xor<S>((int)(unsigned)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+template <int R>
+struct FastK {
+    u64 e[R];
+};
+
+template <int R, int SIZE, int STRIDE, bool DESC>
+__device__ __forceinline__ void fast_level(FastK<R>& t) {
+    const int lane = lane_id();
+    if constexpr (STRIDE >= 64) {
+        constexpr int ds = STRIDE >> 6;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            if ((r & ds) == 0 && (r | ds) < R) {
+                const int r2 = r | ds;
+                const bool asc = (((64 * r) & SIZE) == 0) != DESC;     // SIZE >= 128 here: depends on the slot only
+                const u64 lo = t.e[r] < t.e[r2] ? t.e[r] : t.e[r2];
+                const u64 hi = t.e[r] < t.e[r2] ? t.e[r2] : t.e[r];
+                t.e[r] = asc ? lo : hi;
+                t.e[r2] = asc ? hi : lo;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const u64 pk = lane_xor64<STRIDE>(t.e[r]);
+            const bool asc = (((lane + 64 * r) & SIZE) == 0) != DESC;
+            const bool keep_min = ((lane & STRIDE) == 0) == asc;        // lane-constant: hoisted into a scalar mask
+            const bool take = (pk < t.e[r]) == keep_min;                // keys are unique (payload), no tie case
+            t.e[r] = take ? pk : t.e[r];
+        }
+    }
+}
+
+template <int R, int SIZE, int STRIDE, bool DESC>
+__device__ __forceinline__ void fast_strides(FastK<R>& t) {
+    fast_level<R, SIZE, STRIDE, DESC>(t);
+    if constexpr (STRIDE > 1) fast_strides<R, SIZE, STRIDE / 2, DESC>(t);
+}
+
+template <int R, int SIZE, bool DESC>
+__device__ __forceinline__ void fast_sort_from(FastK<R>& t) {
+    fast_strides<R, SIZE, SIZE / 2, DESC>(t);
+    if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2, DESC>(t);
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
+                                                                  int items_q, int* __restrict__ redo,
+                                                                  int* __restrict__ redo_count) {
+    __shared__ float4 s_cand[kWavesPerBlock][kStageCap];      // {x,y,z, sorted position}
+    __shared__ u64 s_pend[kWavesPerBlock][64 * R + 64];
+
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w;
+    if (item >= n_items) return;
+
+    const pct_grid g = a.g;
+    const int* __restrict__ cs = a.cell_start;
+    const int2 it2 = items[item];
+    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+    const int cx = cell % g.nx;
+    const int cy = (cell / g.nx) % g.ny;
+    const int cz = cell / (g.nx * g.ny);
+    const int qs = cs[cell] + chunk * items_q;
+    const int qe = min(cs[cell + 1], qs + items_q);
+
+    // ---- stage the 27-cell stencil (9 x-runs of <= 3 consecutive cells), centre row first.
+    // Lanes 0..8 fetch the run bounds in parallel; the runs are then copied as one flat
+    // range so that all global loads of the item are in flight together.
+    float4* cand = s_cand[w];
+    u64* pend = s_pend[w];
+    int run_s = 0, run_len = 0;
+    if (lane < 9) {
+        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+        if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+            const int row = (z * g.ny + y) * g.nx;
+            run_s = cs[row + max(cx - 1, 0)];
+            run_len = cs[row + min(cx + 1, g.nx - 1) + 1] - run_s;
+        }
+    }
+    int pre[10], off[9];
+    pre[0] = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        pre[t + 1] = pre[t] + __builtin_amdgcn_readlane(run_len, t);
+        off[t] = __builtin_amdgcn_readlane(run_s, t) - pre[t];           // sorted position = flat slot + off[t]
+    }
+    const int m = pre[9];
+    const bool staged = m <= kStageCap;
+    {
+        float4 tmp[kStageCap / 64];
+#pragma unroll
+        for (int b = 0; b < kStageCap / 64; ++b) {
+            const int j = b * 64 + lane;
+            int o = off[0];
+#pragma unroll
+            for (int t = 1; t < 9; ++t) o = j >= pre[t] ? off[t] : o;
+            const int pos = j + o;
+            tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (j < m) {
+                tmp[b] = a.pts[pos];
+                tmp[b].w = __int_as_float(pos);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < kStageCap / 64; ++b) {
+            const int j = b * 64 + lane;
+            if (j < m) cand[j] = tmp[b];
+        }
+    }
+    // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
+    const int nq = qe - qs;
+    float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    double4 my_qd = make_double4(0., 0., 0., 0.);
+    if (lane < nq) {
+        my_q = a.pts[qs + lane];
+        if (a.ptsd) my_qd = a.ptsd[qs + lane];
+    }
+    wave_lds_sync();
+    const int k = a.k;
+    const double eps2 = a.eps2;
+
+    unsigned long long n_fallback = 0, n_flush = 0, n_step = 0, n_redo = 0;
+
+    for (int qi = 0; qi < nq; ++qi) {
+        const int q = qs + qi;
+        const int pub = __builtin_amdgcn_readlane(__float_as_int(my_q.w), qi);
+        if (pub < a.q_begin || pub >= a.q_end) continue;
+        double qx, qy, qz;
+        if (a.ptsd) {
+            qx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.x), qi), __builtin_amdgcn_readlane(__double2loint(my_qd.x), qi));
+            qy = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.y), qi), __builtin_amdgcn_readlane(__double2loint(my_qd.y), qi));
+            qz = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.z), qi), __builtin_amdgcn_readlane(__double2loint(my_qd.z), qi));
+        } else {
+            qx = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+            qy = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+            qz = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+        }
+        const double gx = (qx - g.ox) * g.inv_cell - cx;
+        const double gy = (qy - g.oy) * g.inv_cell - cy;
+        const double gz = (qz - g.oz) * g.inv_cell - cz;
+
+        FastK<R> best;
+#pragma unroll
+        for (int r = 0; r < R; ++r) best.e[r] = kPadKey;
+        u64 tau = kPadKey;               // element k of best (wave-uniform)
+        int npend = 0;
+        bool empty = true;
+        bool amb = false;                // per-lane: a float-key collision that could matter was seen
+
         bool from_lds = staged;
-        bool full_cube = !staged;      // ring 1 from global: every row is a full x-run
         int base = 0;
-        int it_dz = -1, it_dy = -1, it_part = 0, seg_pos = 0, seg_end = 0;
+        ShellIter it;
+        it.start(1, true);
+        float4 c_next = make_float4(0.f, 0.f, 0.f, 0.f);     // LDS read of the next step, issued one step ahead
+        if (from_lds && lane < m) c_next = cand[lane];
 
         for (;;) {
             bool have = false, valid = false;
             float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            int pos = 0;
+            unsigned payload = 0;
             if (from_lds) {
                 if (base < m) {
                     const int slot = base + lane;
                     valid = slot < m;
-                    if (valid) { c = cand[slot]; pos = __float_as_int(c.w); }
+                    c = c_next;
+                    payload = (unsigned)slot;
                     base += 64;
+                    if (base + lane < m) c_next = cand[base + lane];
                     have = true;
                 }
             } else {
-                // advance to the next non-empty x-run of the current ring
-                while (seg_pos >= seg_end && it_dz <= ring) {
-                    const int z = cz + it_dz, y = cy + it_dy;
-                    const bool face = full_cube || it_dz == -ring || it_dz == ring || it_dy == -ring || it_dy == ring;
-                    int s = 0, e = 0;
-                    if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-                        const int row = (z * g.ny + y) * g.nx;
-                        if (face) {
-                            s = cs[row + max(cx - ring, 0)];
-                            e = cs[row + min(cx + ring, g.nx - 1) + 1];
-                        } else if (it_part == 0) {
-                            if (cx - ring >= 0) { s = cs[row + cx - ring]; e = cs[row + cx - ring + 1]; }
-                        } else {
-                            if (cx + ring < g.nx) { s = cs[row + cx + ring]; e = cs[row + cx + ring + 1]; }
-                        }
-                    }
-                    if (face || it_part == 1) {
-                        it_part = 0;
-                        if (++it_dy > ring) { it_dy = -ring; ++it_dz; }
-                    } else {
-                        it_part = 1;
-                    }
-                    seg_pos = s;
-                    seg_end = e;
-                }
-                if (seg_pos < seg_end) {
-                    pos = seg_pos + lane;
-                    valid = pos < seg_end;
+                int b0 = 0, lim = 0;
+                if (it.next(g, cs, cx, cy, cz, b0, lim)) {
+                    const int pos = b0 + lane;
+                    valid = pos < lim;
                     if (valid) c = a.pts[pos];
-                    seg_pos += 64;
+                    payload = 0x80000000u | (unsigned)pos;
                     have = true;
                 }
             }
             if (have) {
-                sw.consider(c, pos, valid);
+                const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
+                const double d2 = (dx * dx + dy * dy) + dz * dz;
+                const unsigned key = __float_as_uint((float)d2);
+                const u64 e = ((u64)key << 32) | payload;
+                const bool in_eps = valid && d2 < eps2;
+                const bool pass = in_eps && e < tau;
+                amb |= in_eps && key == (unsigned)(tau >> 32);
+                const unsigned long long mask = __ballot(pass);
+                if (pass) {
+                    const int slot = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    pend[slot] = e;
+                }
+                npend += __popcll(mask);
                 ++n_step;
-                if (sw.npend < 64 * R) continue;
+                if (npend < 64 * R) continue;
             }
-            if (sw.npend > 0 || sw.empty) {     // the ONE flush site
-                sw.flush();
+            if (npend > 0 || empty) {     // the ONE flush site
+                FastK<R> b;
+                wave_lds_sync();
+                const int take = npend < 64 * R ? npend : 64 * R;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    b.e[r] = i < take ? pend[i] : kPadKey;
+                }
+                const int rest = npend - take;
+                u64 mv = 0;
+                if (lane < rest) mv = pend[take + lane];
+                wave_lds_sync();
+                if (lane < rest) pend[lane] = mv;
+                wave_lds_sync();
+                npend = rest;
+                fast_sort_from<R, 2, true>(b);                 // descending
+                // a first batch meets an all-padding list: the same merge then simply reverses it
+#pragma unroll
+                for (int r = 0; r < R; ++r) best.e[r] = b.e[r] < best.e[r] ? b.e[r] : best.e[r];
+                fast_strides<R, 64 * R, 32 * R, false>(best);
+                empty = false;
+                // threshold = element k; the tail beyond it must not share its float key
+                {
+                    const int slot = k >> 6, src = k & 63;
+                    u64 v = best.e[0];
+#pragma unroll
+                    for (int r = 1; r < R; ++r)
+                        if (slot == r) v = best.e[r];
+                    const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
+                    const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
+                    tau = ((u64)thi << 32) | tlo;
+                    const unsigned last_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best.e[R - 1] >> 32), 63);
+                    amb |= (tau != kPadKey) && last_hi == thi;
+                }
                 ++n_flush;
             }
             if (have) continue;
 
             // ring exhausted: is every point closer than the (k+1)-th best inside the searched cube?
-            const double inf = INFINITY;
-            double gmin = inf;
-            gmin = fmin(gmin, cx - ring <= 0 ? inf : gx + ring);
-            gmin = fmin(gmin, cx + ring >= g.nx - 1 ? inf : (1.0 - gx) + ring);
-            gmin = fmin(gmin, cy - ring <= 0 ? inf : gy + ring);
-            gmin = fmin(gmin, cy + ring >= g.ny - 1 ? inf : (1.0 - gy) + ring);
-            gmin = fmin(gmin, cz - ring <= 0 ? inf : gz + ring);
-            gmin = fmin(gmin, cz + ring >= g.nz - 1 ? inf : (1.0 - gz) + ring);
-            const double rr = gmin * g.cell * (1.0 - 1e-6);
-            const double need = fmin(sw.tau_d, sw.eps2);
-            if (need <= rr * rr) break;
-            ++ring;
-            if (ring == 2) ++n_fallback;
-            from_lds = false;
-            full_cube = false;
-            it_dz = -ring; it_dy = -ring; it_part = 0;
-            seg_pos = seg_end = 0;
+            const unsigned thi = (unsigned)(tau >> 32);
+            const double tau_ub = tau == kPadKey ? (double)INFINITY : (double)__uint_as_float(thi + 1u);   // next float up >= exact d2
+            const int ring = from_lds ? 1 : it.ring;
+            if (fmin(tau_ub, eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, ring)) break;
+            if (ring == 1) ++n_fallback;
+            if (from_lds) {
+                from_lds = false;
+                it.start(2, false);
+            } else {
+                it.start(ring + 1, false);
+            }
         }
-        sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+
+        // ---- neighbours with equal float keys inside the first k+2 entries: order not proven
+        {
+            u64 nxt[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                u64 up = __shfl_down(best.e[r], 1);                          // element i+1 for lanes 0..62
+                if (r + 1 < R) {
+                    const u64 first_next = __shfl(best.e[r + 1 < R ? r + 1 : r], 0);
+                    if (lane == 63) up = first_next;
+                } else if (lane == 63) {
+                    up = kPadKey;
+                }
+                nxt[r] = up;
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                amb |= i <= k && best.e[r] != kPadKey && (unsigned)(best.e[r] >> 32) == (unsigned)(nxt[r] >> 32);
+            }
+        }
+        if (__ballot(amb) != 0ull) {
+            if (lane == 0) redo[atomicAdd(redo_count, 1)] = q;
+            ++n_redo;
+            continue;
+        }
+
+        // ---- store: exact fp64 distance re-derived from the coordinates -------
+        int found = 0;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int i = lane + 64 * r;
+            if (i >= 1 && i <= k) {
+                const u64 e = best.e[r];
+                const bool real = e != kPadKey;
+                const unsigned payload = (unsigned)e;
+                int pos = -1;
+                float dist = INFINITY;
+                if (real) {
+                    float4 c;
+                    if (payload & 0x80000000u) {
+                        pos = (int)(payload & 0x7fffffffu);
+                        c = a.pts[pos];
+                    } else {
+                        c = cand[payload];
+                        pos = __float_as_int(c.w);
+                    }
+                    const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
+                    dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
+                }
+                a.nbr_pos[(int64_t)q * k + (i - 1)] = pos;
+                a.nbr_dist[(int64_t)q * k + (i - 1)] = dist;
+                found += real;
+            }
+        }
+        if (a.nbr_cnt) {
+            for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
+            if (lane == 0) a.nbr_cnt[q] = found;
+        }
     }
-    if (lane == 0) {
+    // statistics are opt-in: ~10^5 waves adding to the same words serialise at the memory side
+    if (a.stats && lane == 0) {
         if (n_fallback) atomicAdd(&a.counters[0], n_fallback);
         if (!staged) atomicAdd(&a.counters[1], 1ull);
         atomicAdd(&a.counters[2], n_flush);
         atomicAdd(&a.counters[3], n_step);
+        if (n_redo) atomicAdd(&a.counters[4], n_redo);
     }
 }
 
@@ -529,6 +846,7 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     a.nbr_dist = (float*)ctx->nbr_dist.p;
     a.nbr_cnt = eps > 0 ? (int*)ctx->nbr_cnt.p : nullptr;
     a.counters = (unsigned long long*)ctx->counters.p;
+    a.stats = ctx->collect_stats ? 1 : 0;
     return a;
 }
 
@@ -543,15 +861,34 @@ int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
 
 }  // namespace
 
-int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps) {
+int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     PCT_TRY(reserve_table(ctx, k, eps));
+    PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)ctx->n + 16) * sizeof(int)));
     KnnArgs a = make_args(ctx, k, eps, true);
-    const int blocks = (int)((ctx->n_occ + kWavesPerBlock - 1) / kWavesPerBlock);
-    if (blocks > 0) {
+    int* redo_count = (int*)ctx->counters.p + 14;            // counters buffer: 8 x u64, last int pair reserved
+    int* redo = (int*)ctx->redo.p;
+    const dim3 block(64 * kWavesPerBlock);
+    if (!exact_only) {
+        const int blocks = (int)((ctx->n_items + kWavesPerBlock - 1) / kWavesPerBlock);
+        if (blocks > 0) {
+            if (k + 1 <= 64)
+                hipLaunchKernelGGL(k_knn_fast<1>, dim3(blocks), block, 0, ctx->stream, a, (const int2*)ctx->occ.p,
+                                   ctx->n_items, ctx->items_q, redo, redo_count);
+            else
+                hipLaunchKernelGGL(k_knn_fast<2>, dim3(blocks), block, 0, ctx->stream, a, (const int2*)ctx->occ.p,
+                                   ctx->n_items, ctx->items_q, redo, redo_count);
+            PCT_HIP(ctx, hipGetLastError());
+        }
+    }
+    // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
+    {
+        const int64_t waves = exact_only ? ctx->n : 8192;
+        const int blocks = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+        const int* list = exact_only ? nullptr : redo;
         if (k + 1 <= 64)
-            hipLaunchKernelGGL(k_knn_grid<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_knn_exact<1>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
         else
-            hipLaunchKernelGGL(k_knn_grid<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
+            hipLaunchKernelGGL(k_knn_exact<2>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
         PCT_HIP(ctx, hipGetLastError());
     }
     ctx->knn_sorted_space = true;

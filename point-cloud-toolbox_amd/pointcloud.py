@@ -26,6 +26,9 @@ from . import _capi
 
 __all__ = ["PointCloud"]
 
+_ALGORITHMS = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID,
+               "grid_exact": _capi.KNN_GRID_EXACT}
+
 
 class PointCloud:
 
@@ -45,6 +48,7 @@ class PointCloud:
         self._user_neighbors = None
         self._fit_on_device = False
         self.eps = None
+        self.collect_stats = False      # sweep statistics in last_timings (costs atomics)
 
         if file_path:
             self.file_path = file_path
@@ -81,6 +85,7 @@ class PointCloud:
     def _ctx(self):
         if self._handle is None:
             self._handle = _capi.Handle(self._device)      # raises without library / GPU
+            self._handle.set_stats(self.collect_stats)
         if not self._cloud_on_device:
             pts = np.asarray(self.points)
             if pts.ndim != 2 or pts.shape[1] != 3:
@@ -107,7 +112,7 @@ class PointCloud:
         """
         self.k_neighbors = k_neighbors                      # pct:71
         self.eps = eps
-        algo = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID}[algorithm]
+        algo = _ALGORITHMS[algorithm]
         h = self._ctx()
         h.knn(k_neighbors, eps or 0.0, algo)
         self._nbr_cache = None
@@ -181,7 +186,7 @@ class PointCloud:
     def compute_curvature_fused(self, k_neighbors, eps=None, algorithm="auto"):
         self.k_neighbors = k_neighbors
         self.eps = eps
-        algo = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID}[algorithm]
+        algo = _ALGORITHMS[algorithm]
         h = self._ctx()
         h.curvature(k_neighbors, eps or 0.0, algo)
         self._nbr_cache = None

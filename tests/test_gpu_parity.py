@@ -26,6 +26,7 @@ def assert_curvature(K, H, refK, refH, mask=None):
 
 def run_cloud(gpu, pts, k, algorithm="auto", eps=None):
     pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.collect_stats = True
     pc.plant_kdtree(k, eps=eps, algorithm=algorithm)
     K, H = pc.compute_pointwise_explicit_quadratic_curvature()
     return pc, K, H
@@ -126,6 +127,28 @@ def test_brute_and_grid_agree_bitwise(gpu):
     assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
 
 
+@pytest.mark.parametrize("k", [20, 50, 100])
+def test_exact_sweep_matches_fast_sweep(gpu, k):
+    """The float-key fast sweep (+ redo of flagged queries) and the all-exact sweep agree bit for bit."""
+    pts = gpu["shapes"].torus_random(30_000, seed=55)
+    a, Ka, Ha = run_cloud(gpu, pts, k, "grid")
+    b, Kb, Hb = run_cloud(gpu, pts, k, "grid_exact")
+    assert np.array_equal(a.neighbor_indices, b.neighbor_indices) and np.array_equal(a.dists, b.dists)
+    assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
+    assert a.last_timings["redone_queries"] < 0.02 * len(pts)       # collisions of float keys are rare
+
+
+def test_lattice_goes_through_the_exact_redo(gpu, golden):
+    g = golden("g5_egggrid64_k30.npz")
+    pc = gpu["PointCloud"](points=g["points"], normals=np.zeros((len(g["points"]), 0)))
+    pc.collect_stats = True
+    pc.plant_kdtree(30, algorithm="grid")
+    assert pc.last_timings["redone_queries"] > 0                       # exact ties exist on a lattice
+    ex = gpu["PointCloud"](points=g["points"], normals=np.zeros((len(g["points"]), 0)))
+    ex.plant_kdtree(30, algorithm="brute")
+    assert np.array_equal(pc.neighbor_indices, ex.neighbor_indices) and np.array_equal(pc.dists, ex.dists)
+
+
 @pytest.mark.parametrize("shape,k", [("sphere", 30), ("torus", 50), ("egg", 50)])
 def test_pipeline_vs_oracle_100k(gpu, shape, k):
     sh = gpu["shapes"]
@@ -165,6 +188,7 @@ def test_density_contrast_forces_ring_fallback_and_lds_overflow(gpu):
     pts = np.vstack([dense, sparse]).astype(np.float32)
     pts = pts[rng.permutation(len(pts))]
     pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.collect_stats = True
     pc.plant_kdtree(50, algorithm="grid")
     t = pc.last_timings
     idx, d = oracle.knn(pts, 50)

@@ -10,6 +10,8 @@ k = int(sys.argv[2]) if len(sys.argv) > 2 else 50
 pts = shapes.torus_random(n, seed=1234)
 h = _capi.Handle(0)
 h.set_points(pts)
+stats = os.environ.get('PCT_STATS', '0') == '1'
+h.set_stats(stats)
 for f in [float(x) for x in (sys.argv[3:] or "0.2 0.25 0.3 0.35 0.4 0.45 0.55".split())]:
     h.set_grid_param(f)
     best = None
