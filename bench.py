@@ -148,7 +148,7 @@ def main():
                                    "fused plane-align/quadric-fit/curvature (BASELINE configs[2])",
                        "points_total": n_total, "k": k,
                        "parallelism": f"point-index-range shards x{world}" + (" + RCCL all-gather of coordinates" if world > 1 else "")},
-            "roofline": {"bound": "hbm", "kernel": "k_knn_grid", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+            "roofline": {"bound": "hbm", "kernel": "k_knn_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": knn_ms / steps},
             "stage_ms": {"grid_build": grid_ms / steps, "knn": knn_ms / steps, "fit_curvature": fit_ms / steps},

@@ -289,7 +289,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     float bbox[6];
     PCT_TRY(pct_pack_points(ctx, bbox));
 
-    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : 0.45;
+    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : 0.5;
     const double target = factor * (k + 1);
     const int64_t cell_cap = (int64_t)1 << 27;
 
