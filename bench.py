@@ -26,6 +26,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def measured_traffic(n_points, k):
+    """HBM bytes per sweep launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_d_knn_traffic.json")) as f:
+            d = json.load(f)
+        if n_points == 1_000_000 and k == 50:
+            return d["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(pts, k, seconds_target=15.0):
     """1-core reference-faithful port (oracle loop) on a bounded sample of the same cloud."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -149,7 +161,7 @@ def main():
                        "points_total": n_total, "k": k,
                        "parallelism": f"point-index-range shards x{world}" + (" + RCCL all-gather of coordinates" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_knn_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(nq, k),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": knn_ms / steps},
             "stage_ms": {"grid_build": grid_ms / steps, "knn": knn_ms / steps, "fit_curvature": fit_ms / steps},
             "target_points_per_s": 1e7,

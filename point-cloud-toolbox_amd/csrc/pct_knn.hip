@@ -26,7 +26,10 @@
 namespace {
 
 constexpr int kWavesPerBlock = 4;
-constexpr int kStageCap = 512;   // LDS-staged stencil candidates per wave
+#ifndef PCT_STAGE_CAP
+#define PCT_STAGE_CAP 448
+#endif
+constexpr int kStageCap = PCT_STAGE_CAP;   // LDS-staged stencil candidates per wave and per 64 list slots (12 B each, SoA)
 
 struct KnnArgs {
     const float4* pts;        // candidate records {x,y,z,public index}; cell-sorted (grid) or public order (brute)
@@ -399,6 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, it.ring)) break;
             it.start(it.ring + 1, false);
         }
+        if (a.stats && lane == 0 && it.ring > 1) atomicAdd(&a.counters[0], 1ull);
         sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
     }
 }
@@ -406,32 +410,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
 // ---------------------------------------------------------------------------
 // Fast sweep: wave = work item (one cell, <= items_q consecutive queries).
 //
-// Elements of the wave-wide network are single 64-bit integers
-//     (float32 bits of the fp64 squared distance) << 32 | payload
-// payload = LDS slot of a staged candidate, or 0x80000000 | sorted position of
-// a candidate streamed from global.  float(d2) is a monotone map of the exact
-// fp64 value, so wherever two float keys differ the order is the exact order.
-// Every situation in which a float key collision could influence the k+1
-// smallest (a rejected or dropped candidate sharing the threshold's float key,
-// equal neighbours in the final list) raises a flag; flagged queries are
-// appended to the redo list and re-done by k_knn_exact.  Unflagged results are
-// therefore bit-identical to the exact path: the stored distance is recomputed
-// in fp64 from the coordinates.  One compare-exchange level costs two DPP moves,
-// one 64-bit integer compare, one scalar mask op and two selects.
+// Elements of the wave-wide network are single 32-bit integers
+//     key << SLOT_BITS | slot
+// slot = LDS slot of a staged stencil candidate; key = floor(d2 * scale) with the
+// exact fp64 squared distance d2 and scale = 2^KEY_BITS / (12.1 cell^2), the
+// largest squared distance the 27-cell stencil can hold.  The quantisation is a
+// monotone map of the exact value, so wherever two keys differ the order is the
+// exact order.  Every situation in which a key collision could influence the k+1
+// smallest (a rejected or dropped candidate sharing the threshold's key, equal
+// neighbours in the final list) raises a flag; flagged queries -- and queries
+// whose answer is not guaranteed to lie inside the stencil, and whole items
+// whose stencil does not fit the LDS staging area -- are appended to the redo
+// list and done by k_knn_exact.  Unflagged results are therefore bit-identical
+// to the exact path: the stored distance is recomputed in fp64 from the
+// coordinates.  One compare-exchange level costs one DPP move (or one
+// v_permlane swap), one 32-bit compare, one scalar mask op and one select.
 // ---------------------------------------------------------------------------
-typedef unsigned long long u64;
-constexpr u64 kPadKey = ~0ull;
-
-template <int S>
-__device__ __forceinline__ u64 lane_xor64(u64 v) {
-    const unsigned lo = (unsigned)lane_xor<S>((int)(unsigned)v);
-    const unsigned hi = (unsigned)lane_xor<S>((int)(unsigned)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
+constexpr unsigned kPadElem = 0xFFFFFFFFu;
 
 template <int R>
 struct FastK {
-    u64 e[R];
+    unsigned e[R];
 };
 
 template <int R, int SIZE, int STRIDE, bool DESC>
@@ -444,8 +443,8 @@ __device__ __forceinline__ void fast_level(FastK<R>& t) {
             if ((r & ds) == 0 && (r | ds) < R) {
                 const int r2 = r | ds;
                 const bool asc = (((64 * r) & SIZE) == 0) != DESC;     // SIZE >= 128 here: depends on the slot only
-                const u64 lo = t.e[r] < t.e[r2] ? t.e[r] : t.e[r2];
-                const u64 hi = t.e[r] < t.e[r2] ? t.e[r2] : t.e[r];
+                const unsigned lo = min(t.e[r], t.e[r2]);
+                const unsigned hi = max(t.e[r], t.e[r2]);
                 t.e[r] = asc ? lo : hi;
                 t.e[r2] = asc ? hi : lo;
             }
@@ -453,10 +452,10 @@ __device__ __forceinline__ void fast_level(FastK<R>& t) {
     } else {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const u64 pk = lane_xor64<STRIDE>(t.e[r]);
+            const unsigned pk = (unsigned)lane_xor<STRIDE>((int)t.e[r]);
             const bool asc = (((lane + 64 * r) & SIZE) == 0) != DESC;
             const bool keep_min = ((lane & STRIDE) == 0) == asc;        // lane-constant: hoisted into a scalar mask
-            const bool take = (pk < t.e[r]) == keep_min;                // keys are unique (payload), no tie case
+            const bool take = (pk < t.e[r]) == keep_min;                // elements are unique (slot bits): no tie case
             t.e[r] = take ? pk : t.e[r];
         }
     }
@@ -478,8 +477,14 @@ template <int R>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
-    __shared__ float4 s_cand[kWavesPerBlock][kStageCap];      // {x,y,z, sorted position}
-    __shared__ u64 s_pend[kWavesPerBlock][64 * R + 64];
+    constexpr int CAP = kStageCap * R;                 // staged stencil candidates per wave
+    constexpr int SLOT_BITS = R == 1 ? 9 : 10;
+    constexpr int KEY_BITS = 32 - SLOT_BITS;
+    static_assert(CAP <= (1 << SLOT_BITS), "slot field too narrow");
+    __shared__ float s_cx[kWavesPerBlock][CAP];        // staged stencil, structure of arrays:
+    __shared__ float s_cy[kWavesPerBlock][CAP];        // 12 B per candidate
+    __shared__ float s_cz[kWavesPerBlock][CAP];
+    __shared__ unsigned s_pend[kWavesPerBlock][64 * R + 64];
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -496,12 +501,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     const int cz = cell / (g.nx * g.ny);
     const int qs = cs[cell] + chunk * items_q;
     const int qe = min(cs[cell + 1], qs + items_q);
+    const int nq = qe - qs;
 
-    // ---- stage the 27-cell stencil (9 x-runs of <= 3 consecutive cells), centre row first.
-    // Lanes 0..8 fetch the run bounds in parallel; the runs are then copied as one flat
-    // range so that all global loads of the item are in flight together.
-    float4* cand = s_cand[w];
-    u64* pend = s_pend[w];
+    // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+    float* cand_x = s_cx[w];
+    float* cand_y = s_cy[w];
+    float* cand_z = s_cz[w];
+    unsigned* pend = s_pend[w];
     int run_s = 0, run_len = 0;
     if (lane < 9) {
         const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
@@ -511,6 +517,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             run_len = cs[row + min(cx + 1, g.nx - 1) + 1] - run_s;
         }
     }
+    // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
+    float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    double4 my_qd = make_double4(0., 0., 0., 0.);
+    if (lane < nq) {
+        my_q = a.pts[qs + lane];
+        if (a.ptsd) my_qd = a.ptsd[qs + lane];
+    }
     int pre[10], off[9];
     pre[0] = 0;
 #pragma unroll
@@ -519,41 +532,49 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         off[t] = __builtin_amdgcn_readlane(run_s, t) - pre[t];           // sorted position = flat slot + off[t]
     }
     const int m = pre[9];
-    const bool staged = m <= kStageCap;
+    unsigned long long n_flush = 0, n_step = 0, n_redo = 0;
+
+    if (m > CAP) {
+        // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
+        const int pub = __float_as_int(my_q.w);
+        const bool mine = lane < nq && pub >= a.q_begin && pub < a.q_end;
+        const unsigned long long mk = __ballot(mine);
+        if (mk) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(redo_count, (int)__popcll(mk));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (mine) redo[base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] = qs + lane;
+        }
+        if (a.stats && lane == 0) {
+            atomicAdd(&a.counters[1], 1ull);
+            atomicAdd(&a.counters[4], (unsigned long long)__popcll(mk));
+        }
+        return;
+    }
+
+    // ---- copy the runs as one flat range: all global loads of the item are in flight together
     {
-        float4 tmp[kStageCap / 64];
+        float4 tmp[CAP / 64];
 #pragma unroll
-        for (int b = 0; b < kStageCap / 64; ++b) {
+        for (int b = 0; b < CAP / 64; ++b) {
             const int j = b * 64 + lane;
             int o = off[0];
 #pragma unroll
             for (int t = 1; t < 9; ++t) o = j >= pre[t] ? off[t] : o;
-            const int pos = j + o;
             tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < m) {
-                tmp[b] = a.pts[pos];
-                tmp[b].w = __int_as_float(pos);
-            }
+            if (j < m) tmp[b] = a.pts[j + o];
         }
 #pragma unroll
-        for (int b = 0; b < kStageCap / 64; ++b) {
+        for (int b = 0; b < CAP / 64; ++b) {
             const int j = b * 64 + lane;
-            if (j < m) cand[j] = tmp[b];
+            if (j < m) { cand_x[j] = tmp[b].x; cand_y[j] = tmp[b].y; cand_z[j] = tmp[b].z; }
         }
-    }
-    // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
-    const int nq = qe - qs;
-    float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
-    double4 my_qd = make_double4(0., 0., 0., 0.);
-    if (lane < nq) {
-        my_q = a.pts[qs + lane];
-        if (a.ptsd) my_qd = a.ptsd[qs + lane];
     }
     wave_lds_sync();
     const int k = a.k;
     const double eps2 = a.eps2;
-
-    unsigned long long n_fallback = 0, n_flush = 0, n_step = 0, n_redo = 0;
+    const double scale = (double)(1u << KEY_BITS) / (12.1 * g.cell * g.cell);
+    const unsigned key_max = (1u << KEY_BITS) - 1u;
 
     for (int qi = 0; qi < nq; ++qi) {
         const int q = qs + qi;
@@ -569,137 +590,97 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             qy = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
             qz = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
         }
-        const double gx = (qx - g.ox) * g.inv_cell - cx;
-        const double gy = (qy - g.oy) * g.inv_cell - cy;
-        const double gz = (qz - g.oz) * g.inv_cell - cz;
 
         FastK<R> best;
 #pragma unroll
-        for (int r = 0; r < R; ++r) best.e[r] = kPadKey;
-        u64 tau = kPadKey;               // element k of best (wave-uniform)
+        for (int r = 0; r < R; ++r) best.e[r] = kPadElem;
+        unsigned tau = kPadElem;         // element k of best (wave-uniform)
         int npend = 0;
-        bool empty = true;
-        bool amb = false;                // per-lane: a float-key collision that could matter was seen
+        bool amb = false;                // per-lane: a key collision that could matter was seen
 
-        bool from_lds = staged;
-        int base = 0;
-        ShellIter it;
-        it.start(1, true);
-        float4 c_next = make_float4(0.f, 0.f, 0.f, 0.f);     // LDS read of the next step, issued one step ahead
-        if (from_lds && lane < m) c_next = cand[lane];
+        float cnx = 0.f, cny = 0.f, cnz = 0.f;                  // LDS reads of the next step, issued one step ahead
+        if (lane < m) { cnx = cand_x[lane]; cny = cand_y[lane]; cnz = cand_z[lane]; }
 
-        for (;;) {
-            bool have = false, valid = false;
-            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned payload = 0;
-            if (from_lds) {
-                if (base < m) {
-                    const int slot = base + lane;
-                    valid = slot < m;
-                    c = c_next;
-                    payload = (unsigned)slot;
-                    base += 64;
-                    if (base + lane < m) c_next = cand[base + lane];
-                    have = true;
-                }
-            } else {
-                int b0 = 0, lim = 0;
-                if (it.next(g, cs, cx, cy, cz, b0, lim)) {
-                    const int pos = b0 + lane;
-                    valid = pos < lim;
-                    if (valid) c = a.pts[pos];
-                    payload = 0x80000000u | (unsigned)pos;
-                    have = true;
-                }
-            }
+        for (int base = 0;; base += 64) {
+            const bool have = base < m;
             if (have) {
-                const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
+                const int slot = base + lane;
+                const bool valid = slot < m;
+                const double dx = (double)cnx - qx, dy = (double)cny - qy, dz = (double)cnz - qz;
+                if (slot + 64 < m) { cnx = cand_x[slot + 64]; cny = cand_y[slot + 64]; cnz = cand_z[slot + 64]; }
                 const double d2 = (dx * dx + dy * dy) + dz * dz;
-                const unsigned key = __float_as_uint((float)d2);
-                const u64 e = ((u64)key << 32) | payload;
+                const unsigned key = min((unsigned)(d2 * scale), key_max);
+                const unsigned e = (key << SLOT_BITS) | (unsigned)slot;
                 const bool in_eps = valid && d2 < eps2;
                 const bool pass = in_eps && e < tau;
-                amb |= in_eps && key == (unsigned)(tau >> 32);
+                amb |= in_eps && ((e ^ tau) >> SLOT_BITS) == 0u;
                 const unsigned long long mask = __ballot(pass);
                 if (pass) {
-                    const int slot = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    pend[slot] = e;
+                    const int at = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    pend[at] = e;
                 }
                 npend += __popcll(mask);
                 ++n_step;
                 if (npend < 64 * R) continue;
             }
-            if (npend > 0 || empty) {     // the ONE flush site
+            if (npend > 0) {              // the ONE flush site
                 FastK<R> b;
                 wave_lds_sync();
                 const int take = npend < 64 * R ? npend : 64 * R;
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int i = lane + 64 * r;
-                    b.e[r] = i < take ? pend[i] : kPadKey;
+                    b.e[r] = i < take ? pend[i] : kPadElem;
                 }
                 const int rest = npend - take;
-                u64 mv = 0;
+                unsigned mv = 0;
                 if (lane < rest) mv = pend[take + lane];
                 wave_lds_sync();
                 if (lane < rest) pend[lane] = mv;
                 wave_lds_sync();
                 npend = rest;
                 fast_sort_from<R, 2, true>(b);                 // descending
-                // a first batch meets an all-padding list: the same merge then simply reverses it
+                // (a first batch meets an all-padding list: the same merge then simply reverses it)
 #pragma unroll
-                for (int r = 0; r < R; ++r) best.e[r] = b.e[r] < best.e[r] ? b.e[r] : best.e[r];
+                for (int r = 0; r < R; ++r) best.e[r] = min(b.e[r], best.e[r]);
                 fast_strides<R, 64 * R, 32 * R, false>(best);
-                empty = false;
-                // threshold = element k; the tail beyond it must not share its float key
+                // threshold = element k; the tail beyond it must not share its key
                 {
-                    const int slot = k >> 6, src = k & 63;
-                    u64 v = best.e[0];
+                    const int sl = k >> 6, src = k & 63;
+                    unsigned v = best.e[0];
 #pragma unroll
                     for (int r = 1; r < R; ++r)
-                        if (slot == r) v = best.e[r];
-                    const unsigned tlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, src);
-                    const unsigned thi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), src);
-                    tau = ((u64)thi << 32) | tlo;
-                    const unsigned last_hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(best.e[R - 1] >> 32), 63);
-                    amb |= (tau != kPadKey) && last_hi == thi;
+                        if (sl == r) v = best.e[r];
+                    tau = (unsigned)__builtin_amdgcn_readlane((int)v, src);
+                    const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)best.e[R - 1], 63);
+                    amb |= tau != kPadElem && last != kPadElem && ((last ^ tau) >> SLOT_BITS) == 0u;
                 }
                 ++n_flush;
             }
-            if (have) continue;
-
-            // ring exhausted: is every point closer than the (k+1)-th best inside the searched cube?
-            const unsigned thi = (unsigned)(tau >> 32);
-            const double tau_ub = tau == kPadKey ? (double)INFINITY : (double)__uint_as_float(thi + 1u);   // next float up >= exact d2
-            const int ring = from_lds ? 1 : it.ring;
-            if (fmin(tau_ub, eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, ring)) break;
-            if (ring == 1) ++n_fallback;
-            if (from_lds) {
-                from_lds = false;
-                it.start(2, false);
-            } else {
-                it.start(ring + 1, false);
-            }
+            if (!have) break;
         }
 
-        // ---- neighbours with equal float keys inside the first k+2 entries: order not proven
+        // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up)
         {
-            u64 nxt[R];
+            const double gx = (qx - g.ox) * g.inv_cell - cx;
+            const double gy = (qy - g.oy) * g.inv_cell - cy;
+            const double gz = (qz - g.oz) * g.inv_cell - cz;
+            const double tau_ub = tau == kPadElem ? (double)INFINITY : (double)((tau >> SLOT_BITS) + 1u) / scale;
+            amb |= !(fmin(tau_ub, eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1));
+        }
+        // ---- neighbours with equal keys inside the first k+2 entries: order not proven
+        {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                u64 up = __shfl_down(best.e[r], 1);                          // element i+1 for lanes 0..62
+                unsigned up = __shfl_down(best.e[r], 1);                     // element i+1 for lanes 0..62
                 if (r + 1 < R) {
-                    const u64 first_next = __shfl(best.e[r + 1 < R ? r + 1 : r], 0);
+                    const unsigned first_next = (unsigned)__builtin_amdgcn_readlane((int)best.e[r + 1 < R ? r + 1 : r], 0);
                     if (lane == 63) up = first_next;
                 } else if (lane == 63) {
-                    up = kPadKey;
+                    up = kPadElem;
                 }
-                nxt[r] = up;
-            }
-#pragma unroll
-            for (int r = 0; r < R; ++r) {
                 const int i = lane + 64 * r;
-                amb |= i <= k && best.e[r] != kPadKey && (unsigned)(best.e[r] >> 32) == (unsigned)(nxt[r] >> 32);
+                amb |= i <= k && best.e[r] != kPadElem && up != kPadElem && ((best.e[r] ^ up) >> SLOT_BITS) == 0u;
             }
         }
         if (__ballot(amb) != 0ull) {
@@ -714,21 +695,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r;
             if (i >= 1 && i <= k) {
-                const u64 e = best.e[r];
-                const bool real = e != kPadKey;
-                const unsigned payload = (unsigned)e;
+                const unsigned e = best.e[r];
+                const bool real = e != kPadElem;
                 int pos = -1;
                 float dist = INFINITY;
                 if (real) {
-                    float4 c;
-                    if (payload & 0x80000000u) {
-                        pos = (int)(payload & 0x7fffffffu);
-                        c = a.pts[pos];
-                    } else {
-                        c = cand[payload];
-                        pos = __float_as_int(c.w);
-                    }
-                    const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
+                    const int j = (int)(e & ((1u << SLOT_BITS) - 1u));
+                    const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
+                    int o = off[0];
+#pragma unroll
+                    for (int t = 1; t < 9; ++t) o = j >= pre[t] ? off[t] : o;
+                    pos = j + o;                                      // sorted position of staged slot j
                     dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
                 }
                 a.nbr_pos[(int64_t)q * k + (i - 1)] = pos;
@@ -743,8 +720,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     }
     // statistics are opt-in: ~10^5 waves adding to the same words serialise at the memory side
     if (a.stats && lane == 0) {
-        if (n_fallback) atomicAdd(&a.counters[0], n_fallback);
-        if (!staged) atomicAdd(&a.counters[1], 1ull);
         atomicAdd(&a.counters[2], n_flush);
         atomicAdd(&a.counters[3], n_step);
         if (n_redo) atomicAdd(&a.counters[4], n_redo);

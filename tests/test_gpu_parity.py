@@ -135,7 +135,7 @@ def test_exact_sweep_matches_fast_sweep(gpu, k):
     b, Kb, Hb = run_cloud(gpu, pts, k, "grid_exact")
     assert np.array_equal(a.neighbor_indices, b.neighbor_indices) and np.array_equal(a.dists, b.dists)
     assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
-    assert a.last_timings["redone_queries"] < 0.02 * len(pts)       # collisions of float keys are rare
+    assert a.last_timings["redone_queries"] < 0.1 * len(pts)        # key collisions, ring fallbacks, LDS overflows are rare
 
 
 def test_lattice_goes_through_the_exact_redo(gpu, golden):
