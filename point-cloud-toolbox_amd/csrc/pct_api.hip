@@ -301,9 +301,12 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
         float bbox[6];
         PCT_TRY(pct_pack_points(ctx, bbox));
     }
-    const size_t cells = (size_t)rows * k;
+    // device rows are 16-byte aligned: pitch = k rounded up to a multiple of 4
+    const int32_t pitch = (k + 3) & ~3;
+    const size_t cells = (size_t)rows * pitch;
     PCT_TRY(pct_reserve(ctx, &ctx->stage_a, cells * sizeof(int)));
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, idx, cells * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipMemcpy2DAsync(ctx->stage_a.p, (size_t)pitch * sizeof(int), idx, (size_t)k * sizeof(int),
+                                  (size_t)k * sizeof(int), (size_t)rows, hipMemcpyHostToDevice, ctx->stream));
     if (count) {
         PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)rows * sizeof(int)));
         PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_c.p, count, (size_t)rows * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
@@ -318,7 +321,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     PCT_TRY(pct_reserve(ctx, &ctx->H2, (size_t)rows * sizeof(float)));
     PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     PCT_TRY(pct_launch_fit_rows(ctx, (const int*)ctx->stage_a.p, count ? (const int*)ctx->stage_c.p : nullptr,
-                                query ? (const int64_t*)ctx->stage_d.p : nullptr, rows, k, (float*)ctx->coefs.p,
+                                query ? (const int64_t*)ctx->stage_d.p : nullptr, rows, k, pitch, (float*)ctx->coefs.p,
                                 (float*)ctx->K.p, (float*)ctx->H.p, (float*)ctx->H2.p));
     PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -7,8 +7,9 @@
 //
 // One thread per point (tiny dense per-point algebra, no MFMA).  A 64-thread
 // workgroup stages its 64 neighbour-index rows into LDS with coalesced loads
-// (odd row pitch -> conflict-free column reads), then every lane walks its own
-// row twice:
+// (odd row pitch -> conflict-free column reads; letting every lane stream its
+// own row from global instead was measured 2x slower), then every lane walks
+// its own row twice, gathers issued four neighbours ahead of their use:
 //   pass 1  centred neighbours (native dtype, pct:641) -> fp64 sums -> 3x3
 //           covariance about the neighbour mean, ddof=1 (pct:277) -> cyclic
 //           Jacobi eigen-solve -> normal = eigenvector of the smallest
@@ -37,6 +38,7 @@ struct FitArgs {
     const int64_t* row_query;// (rows) query id into pts per row (nullable -> row)
     int64_t rows;
     int k;
+    int pitch;               // table row pitch in elements, multiple of 4
     int kp;                  // LDS row pitch (odd)
     int out_by_row;          // 1: outputs indexed by row; 0: by public index of the query
     int64_t out_base;        // subtracted from the public index when out_by_row == 0
@@ -47,12 +49,17 @@ struct FitArgs {
     float* H2;
 };
 
+// One Jacobi rotation annihilating a_pq of a symmetric 3x3 (r = third index).
+// With alpha = (a_qq - a_pp)/2 and beta = a_pq the tangent of the rotation is
+// t = sgn(alpha) beta / (|alpha| + sqrt(alpha^2 + beta^2))  (the small root), c = 1/sqrt(1+t^2):
+// one sqrt, one division and one reciprocal square root per rotation.
 #define JACOBI_ROT(app, aqq, apq, arp, arq, vp0, vp1, vp2, vq0, vq1, vq2)          \
     do {                                                                            \
         if (apq != 0.0) {                                                           \
-            const double theta = (aqq - app) / (2.0 * apq);                         \
-            const double t = copysign(1.0, theta) / (fabs(theta) + sqrt(theta * theta + 1.0)); \
-            const double c = 1.0 / sqrt(t * t + 1.0);                               \
+            const double alpha = 0.5 * (aqq - app);                                 \
+            const double beta = apq;                                                \
+            const double t = (alpha >= 0.0 ? beta : -beta) / (fabs(alpha) + sqrt(alpha * alpha + beta * beta)); \
+            const double c = rsqrt(t * t + 1.0);                                    \
             const double s = t * c;                                                 \
             app -= t * apq;                                                         \
             aqq += t * apq;                                                         \
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     // ---- stage 64 index rows, coalesced ---------------------------------
     const int nrow = (int)min((int64_t)kFitBlock, a.rows - row0);
     for (int r = 0; r < nrow; ++r) {
-        const int* src = a.table + (row0 + r) * k;
+        const int* src = a.table + (row0 + r) * a.pitch;
         for (int j = lane; j < k; j += kFitBlock) s_idx[r * kp + j] = src[j];
     }
     __syncthreads();
@@ -134,16 +141,35 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     // ---- pass 1: moments of the centred neighbourhood ---------------------
     double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0, r2max = 0;
     double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
-    for (int j = 0; j < m; ++j) {
-        double x, y, z;
-        load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
-        if (j == 0) { fx = x; fy = y; fz = z; }
-        lx = x; ly = y; lz = z;
-        sx += x; sy += y; sz += z;
-        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
-        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
-        r2max = fmax(r2max, (x * x + y * y) + z * z);
+    // gathers are issued four neighbours ahead of their use (the row walk is latency-bound otherwise)
+#define PASS1_ACC(x, y, z)                                                          \
+    do {                                                                            \
+        sx += x; sy += y; sz += z;                                                  \
+        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);           \
+        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);           \
+        r2max = fmax(r2max, (x * x + y * y) + z * z);                               \
+    } while (0)
+    {
+        int j = 0;
+        for (; j + 4 <= m; j += 4) {
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+            load_centred<F64>(a, my[j + 0], qx, qy, qz, qp.x, qp.y, qp.z, x0, y0, z0);
+            load_centred<F64>(a, my[j + 1], qx, qy, qz, qp.x, qp.y, qp.z, x1, y1, z1);
+            load_centred<F64>(a, my[j + 2], qx, qy, qz, qp.x, qp.y, qp.z, x2, y2, z2);
+            load_centred<F64>(a, my[j + 3], qx, qy, qz, qp.x, qp.y, qp.z, x3, y3, z3);
+            if (j == 0) { fx = x0; fy = y0; fz = z0; }
+            PASS1_ACC(x0, y0, z0); PASS1_ACC(x1, y1, z1); PASS1_ACC(x2, y2, z2); PASS1_ACC(x3, y3, z3);
+            lx = x3; ly = y3; lz = z3;
+        }
+        for (; j < m; ++j) {
+            double x, y, z;
+            load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+            if (j == 0) { fx = x; fy = y; fz = z; }
+            PASS1_ACC(x, y, z);
+            lx = x; ly = y; lz = z;
+        }
     }
+#undef PASS1_ACC
     const double inv_m = 1.0 / (double)m, inv_m1 = 1.0 / (double)(m - 1);
     const double mx = sx * inv_m, my_ = sy * inv_m, mz = sz * inv_m;
     double a00 = (sxx - sx * mx) * inv_m1, a01 = (sxy - sx * my_) * inv_m1, a02 = (sxz - sx * mz) * inv_m1;
@@ -153,8 +179,9 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // v[row][col]
 #pragma unroll 1
     for (int sweep = 0; sweep < 8; ++sweep) {
+        // off-diagonal mass below 1e-22 of the trace: eigenvectors are converged far beyond fp64 round-off
         const double off = fabs(a01) + fabs(a02) + fabs(a12);
-        if (off == 0.0) break;
+        if (off <= 1e-22 * (fabs(a00) + fabs(a11) + fabs(a22))) break;
         JACOBI_ROT(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21);   // (p,q)=(0,1), r=2
         JACOBI_ROT(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);   // (0,2), r=1
         JACOBI_ROT(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);   // (1,2), r=0
@@ -200,40 +227,54 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     for (int i = 0; i < 21; ++i) g[i] = 0;
 #pragma unroll
     for (int i = 0; i < 6; ++i) b[i] = 0;
-    for (int j = 0; j < m; ++j) {
-        double x, y, z;
-        load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
-        const float pa = (float)((r00 * x + r01 * y) + r02 * z);
-        const float pb = (float)((r10 * x + r11 * y) + r12 * z);
-        const float pz = (float)((r20 * x + r21 * y) + r22 * z);
-        double c[6];
-        c[0] = (double)(pa * pa) * s2;
-        c[1] = (double)(pb * pb) * s2;
-        c[2] = (double)(pa * pb) * s2;
-        c[3] = (double)pa * s1;
-        c[4] = (double)pb * s1;
-        c[5] = 1.0;
-        const double zz = (double)pz;
-        int t = 0;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#pragma unroll
-            for (int jj = 0; jj <= i; ++jj) { g[t] = fma(c[i], c[jj], g[t]); ++t; }
-            b[i] = fma(c[i], zz, b[i]);
+#define PASS2_ACC(x, y, z)                                                          \
+    do {                                                                            \
+        const float pa = (float)((r00 * x + r01 * y) + r02 * z);                    \
+        const float pb = (float)((r10 * x + r11 * y) + r12 * z);                    \
+        const float pz = (float)((r20 * x + r21 * y) + r22 * z);                    \
+        double c[6];                                                                \
+        c[0] = (double)(pa * pa) * s2;                                              \
+        c[1] = (double)(pb * pb) * s2;                                              \
+        c[2] = (double)(pa * pb) * s2;                                              \
+        c[3] = (double)pa * s1;                                                     \
+        c[4] = (double)pb * s1;                                                     \
+        c[5] = 1.0;                                                                 \
+        const double zz = (double)pz;                                               \
+        int t = 0;                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 6; ++i) {                             \
+            _Pragma("unroll") for (int jj = 0; jj <= i; ++jj) { g[t] = fma(c[i], c[jj], g[t]); ++t; } \
+            b[i] = fma(c[i], zz, b[i]);                                             \
+        }                                                                           \
+    } while (0)
+    {
+        int j = 0;
+        for (; j + 4 <= m; j += 4) {
+            double x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
+            load_centred<F64>(a, my[j + 0], qx, qy, qz, qp.x, qp.y, qp.z, x0, y0, z0);
+            load_centred<F64>(a, my[j + 1], qx, qy, qz, qp.x, qp.y, qp.z, x1, y1, z1);
+            load_centred<F64>(a, my[j + 2], qx, qy, qz, qp.x, qp.y, qp.z, x2, y2, z2);
+            load_centred<F64>(a, my[j + 3], qx, qy, qz, qp.x, qp.y, qp.z, x3, y3, z3);
+            PASS2_ACC(x0, y0, z0); PASS2_ACC(x1, y1, z1); PASS2_ACC(x2, y2, z2); PASS2_ACC(x3, y3, z3);
+        }
+        for (; j < m; ++j) {
+            double x, y, z;
+            load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+            PASS2_ACC(x, y, z);
         }
     }
+#undef PASS2_ACC
 
     // ---- Cholesky  G = L L^T  (lower triangle packed row-wise), solve -------
     // packed index of (i,j), j<=i : i*(i+1)/2 + j
 #define GI(i, j) ((i) * ((i) + 1) / 2 + (j))
+    double dinv[6];                 // 1 / L_jj
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = g[GI(j, j)];
 #pragma unroll
         for (int p = 0; p < j; ++p) d -= g[GI(j, p)] * g[GI(j, p)];
-        d = sqrt(d);
-        g[GI(j, j)] = d;
-        const double inv = 1.0 / d;
+        const double inv = rsqrt(d);                    // NaN for a non-positive pivot (degenerate neighbourhood)
+        dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
             double s = g[GI(i, j)];
@@ -247,14 +288,14 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         double s = b[i];
 #pragma unroll
         for (int p = 0; p < i; ++p) s -= g[GI(i, p)] * b[p];
-        b[i] = s / g[GI(i, i)];
+        b[i] = s * dinv[i];
     }
 #pragma unroll
     for (int i = 5; i >= 0; --i) {  // L^T x = y
         double s = b[i];
 #pragma unroll
         for (int p = i + 1; p < 6; ++p) s -= g[GI(p, i)] * b[p];
-        b[i] = s / g[GI(i, i)];
+        b[i] = s * dinv[i];
     }
 #undef GI
     const float A = (float)(b[0] * s2), B = (float)(b[1] * s2), C = (float)(b[2] * s2);
@@ -315,6 +356,7 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     a.row_query = nullptr;
     a.rows = n;
     a.k = ctx->k;
+    a.pitch = ctx->nbr_pitch;
     a.out_by_row = 0;
     a.out_base = ctx->q_begin;
     a.q_begin = (int)ctx->q_begin;
@@ -328,7 +370,7 @@ int pct_launch_fit_table(pct_ctx* ctx) {
 
 // fit from caller-supplied neighbour rows (public indices), outputs row-aligned
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query,
-                        int64_t rows, int32_t k, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
+                        int64_t rows, int32_t k, int32_t pitch, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
     FitArgs a = {};
     a.pts = (const float4*)ctx->pts4.p;
     a.ptsd = ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr;
@@ -337,6 +379,7 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
     a.row_query = d_query;
     a.rows = rows;
     a.k = k;
+    a.pitch = pitch;
     a.out_by_row = 1;
     a.out_base = 0;
     a.q_begin = 0;

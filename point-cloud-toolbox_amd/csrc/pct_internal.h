@@ -66,6 +66,7 @@ struct pct_ctx {
     pct_buf nbr_dist;   // float (n,k)
     pct_buf nbr_cnt;    // int32 (n)
     int32_t k = 0;
+    int32_t nbr_pitch = 0;   // row pitch of nbr_pos / nbr_dist in elements (k rounded up to 4)
     double eps = 0.0;
     bool knn_valid = false;
     bool knn_sorted_space = false; // false: rows/ids are public indices (brute force)
@@ -112,7 +113,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
 // fit (pct_fit.hip)
 int pct_launch_fit_table(pct_ctx* ctx);
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt,
-                        const int64_t* d_query, int64_t rows, int32_t k,
+                        const int64_t* d_query, int64_t rows, int32_t k, int32_t pitch,
                         float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);

@@ -40,6 +40,7 @@ struct KnnArgs {
     int64_t n;
     pct_grid g;
     int k;
+    int pitch;                // row pitch of the neighbour table in elements: k rounded up to a multiple of 4
     double eps2;              // +inf when no bound
     int q_begin, q_end;       // owned public index range
     int* nbr_pos;
@@ -253,7 +254,7 @@ struct Sweep {
     }
 
     // rows: element i (1..k) -> output column i-1
-    __device__ __forceinline__ void store(int64_t row, int* nbr_pos, float* nbr_dist, int* nbr_cnt) {
+    __device__ __forceinline__ void store(int64_t row, int pitch, int* nbr_pos, float* nbr_dist, int* nbr_cnt) {
         const int lane = lane_id();
         int found = 0;
 #pragma unroll
@@ -261,8 +262,8 @@ struct Sweep {
             const int i = lane + 64 * r;
             const bool real = best.p[r] != INT_MAX;
             if (i >= 1 && i <= k) {
-                nbr_pos[row * k + (i - 1)] = real ? best.p[r] : -1;
-                nbr_dist[row * k + (i - 1)] = real ? (float)sqrt(best.d[r]) : INFINITY;
+                nbr_pos[row * pitch + (i - 1)] = real ? best.p[r] : -1;
+                nbr_dist[row * pitch + (i - 1)] = real ? (float)sqrt(best.d[r]) : INFINITY;
                 found += real;
             }
         }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             it.start(it.ring + 1, false);
         }
         if (a.stats && lane == 0 && it.ring > 1) atomicAdd(&a.counters[0], 1ull);
-        sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+        sw.store(q, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
     }
 }
 
@@ -708,8 +709,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
                     pos = j + o;                                      // sorted position of staged slot j
                     dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
                 }
-                a.nbr_pos[(int64_t)q * k + (i - 1)] = pos;
-                a.nbr_dist[(int64_t)q * k + (i - 1)] = dist;
+                a.nbr_pos[(int64_t)q * a.pitch + (i - 1)] = pos;
+                a.nbr_dist[(int64_t)q * a.pitch + (i - 1)] = dist;
                 found += real;
             }
         }
@@ -768,13 +769,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_brute(KnnArgs a) {
         if (sw.npend > 0 || sw.empty) sw.flush();
         if (!have) break;
     }
-    sw.store(q, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+    sw.store(q, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
 }
 
 // sorted-space table -> public (rows,k) arrays for public rows [begin,end)
 __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ nbr_pos,
                                                 const float* __restrict__ nbr_dist, const int* __restrict__ nbr_cnt,
-                                                int64_t n, int k, int64_t begin, int64_t end,
+                                                int64_t n, int k, int pitch, int64_t begin, int64_t end,
                                                 int* __restrict__ idx_out, float* __restrict__ dist_out,
                                                 int* __restrict__ cnt_out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -784,9 +785,9 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
     const int pub = __float_as_int(pts[row].w);
     if (pub < begin || pub >= end) return;
     const int64_t o = (int64_t)(pub - begin) * k + j;
-    const int pos = nbr_pos[row * k + j];
+    const int pos = nbr_pos[row * pitch + j];
     if (idx_out) idx_out[o] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
-    if (dist_out) dist_out[o] = nbr_dist[row * k + j];
+    if (dist_out) dist_out[o] = nbr_dist[row * pitch + j];
     if (cnt_out && j == 0) cnt_out[pub - begin] = nbr_cnt ? nbr_cnt[row] : k;
 }
 
@@ -814,6 +815,7 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     a.n = ctx->n;
     a.g = ctx->grid;
     a.k = k;
+    a.pitch = (k + 3) & ~3;
     a.eps2 = eps > 0 ? eps * eps : INFINITY;
     a.q_begin = (int)ctx->q_begin;
     a.q_end = (int)ctx->q_end;
@@ -826,8 +828,9 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
 }
 
 int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
-    PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, (size_t)ctx->n * k * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, (size_t)ctx->n * k * sizeof(float)));
+    ctx->nbr_pitch = (k + 3) & ~3;                        // 16-byte aligned rows (the fit kernel reads int4)
+    PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, (size_t)ctx->n * ctx->nbr_pitch * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, (size_t)ctx->n * ctx->nbr_pitch * sizeof(float)));
     if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, (size_t)ctx->n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
     PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
@@ -893,7 +896,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream, pts, (const int*)ctx->nbr_pos.p,
                        (const float*)ctx->nbr_dist.p, ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n,
-                       ctx->k, begin, end, d_idx, d_dist, d_cnt);
+                       ctx->k, ctx->nbr_pitch, begin, end, d_idx, d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
