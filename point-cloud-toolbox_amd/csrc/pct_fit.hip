@@ -9,7 +9,7 @@
 // workgroup stages its 64 neighbour-index rows into LDS with coalesced loads
 // (odd row pitch -> conflict-free column reads; letting every lane stream its
 // own row from global instead was measured 2x slower), then every lane walks
-// its own row twice, gathers issued four neighbours ahead of their use:
+// its own row twice, gathers issued eight neighbours ahead of their use:
 //   pass 1  centred neighbours (native dtype, pct:641) -> fp64 sums -> 3x3
 //           covariance about the neighbour mean, ddof=1 (pct:277) -> cyclic
 //           Jacobi eigen-solve -> normal = eigenvector of the smallest
@@ -151,15 +151,14 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     } while (0)
     {
         int j = 0;
-        for (; j + 4 <= m; j += 4) {
-            double x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
-            load_centred<F64>(a, my[j + 0], qx, qy, qz, qp.x, qp.y, qp.z, x0, y0, z0);
-            load_centred<F64>(a, my[j + 1], qx, qy, qz, qp.x, qp.y, qp.z, x1, y1, z1);
-            load_centred<F64>(a, my[j + 2], qx, qy, qz, qp.x, qp.y, qp.z, x2, y2, z2);
-            load_centred<F64>(a, my[j + 3], qx, qy, qz, qp.x, qp.y, qp.z, x3, y3, z3);
-            if (j == 0) { fx = x0; fy = y0; fz = z0; }
-            PASS1_ACC(x0, y0, z0); PASS1_ACC(x1, y1, z1); PASS1_ACC(x2, y2, z2); PASS1_ACC(x3, y3, z3);
-            lx = x3; ly = y3; lz = z3;
+        for (; j + 8 <= m; j += 8) {
+            double x[8], y[8], z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load_centred<F64>(a, my[j + u], qx, qy, qz, qp.x, qp.y, qp.z, x[u], y[u], z[u]);
+            if (j == 0) { fx = x[0]; fy = y[0]; fz = z[0]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) PASS1_ACC(x[u], y[u], z[u]);
+            lx = x[7]; ly = y[7]; lz = z[7];
         }
         for (; j < m; ++j) {
             double x, y, z;
@@ -248,13 +247,12 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     } while (0)
     {
         int j = 0;
-        for (; j + 4 <= m; j += 4) {
-            double x0, y0, z0, x1, y1, z1, x2, y2, z2, x3, y3, z3;
-            load_centred<F64>(a, my[j + 0], qx, qy, qz, qp.x, qp.y, qp.z, x0, y0, z0);
-            load_centred<F64>(a, my[j + 1], qx, qy, qz, qp.x, qp.y, qp.z, x1, y1, z1);
-            load_centred<F64>(a, my[j + 2], qx, qy, qz, qp.x, qp.y, qp.z, x2, y2, z2);
-            load_centred<F64>(a, my[j + 3], qx, qy, qz, qp.x, qp.y, qp.z, x3, y3, z3);
-            PASS2_ACC(x0, y0, z0); PASS2_ACC(x1, y1, z1); PASS2_ACC(x2, y2, z2); PASS2_ACC(x3, y3, z3);
+        for (; j + 8 <= m; j += 8) {
+            double x[8], y[8], z[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) load_centred<F64>(a, my[j + u], qx, qy, qz, qp.x, qp.y, qp.z, x[u], y[u], z[u]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) PASS2_ACC(x[u], y[u], z[u]);
         }
         for (; j < m; ++j) {
             double x, y, z;

@@ -99,7 +99,8 @@ __device__ __forceinline__ int cell_coord(double x, double o, double inv, int n)
 }
 
 __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4, int64_t n, pct_grid g,
-                                                 int* __restrict__ cell_of, int* __restrict__ cell_cnt) {
+                                                 int* __restrict__ cell_of, int* __restrict__ rank_of,
+                                                 int* __restrict__ cell_cnt) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pts4[i];
@@ -108,17 +109,7 @@ __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4
     int cz = cell_coord((double)p.z, g.oz, g.inv_cell, g.nz);
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_of[i] = c;
-    atomicAdd(&cell_cnt[c], 1);
-}
-
-// sum over points of the population of their own cell  (= sum_c count_c^2)
-__global__ __launch_bounds__(kBlock) void k_occupancy(const int* __restrict__ cell_of, const int* __restrict__ cell_cnt,
-                                                      int64_t n, unsigned long long* __restrict__ out) {
-    unsigned long long s = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        s += (unsigned)cell_cnt[cell_of[i]];
-    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, s);
+    rank_of[i] = atomicAdd(&cell_cnt[c], 1);      // arrival rank inside the cell: the scatter needs no second atomic
 }
 
 // ---- dual exclusive scan: counts -> starts, ceil(count/items_q) -> work-item rank ------
@@ -139,8 +130,12 @@ __device__ __forceinline__ int2 block_reduce2(int2 v, int2* sh) {
     return t;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cnt, int64_t ncell, int items_q, int2* __restrict__ tmp) {
+// first scan pass; also accumulates sum_c count_c^2 (= sum over points of the population of their own cell),
+// the statistic the cell-size loop steers on
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cnt, int64_t ncell, int items_q, int2* __restrict__ tmp,
+                                                      unsigned long long* __restrict__ sumsq) {
     __shared__ int2 sh[kBlock / 64];
+    unsigned long long sq = 0;
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int2 v = make_int2(0, 0);
     for (int j = 0; j < kScanItems; ++j) {
@@ -148,9 +143,12 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cn
         int x = c < ncell ? cnt[c] : 0;
         v.x += x;
         v.y += (x + items_q - 1) / items_q;
+        sq += (unsigned long long)x * (unsigned)x;
     }
     int2 t = block_reduce2(v, sh);
     if (threadIdx.x == 0) tmp[blockIdx.x] = t;
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    if ((threadIdx.x & 63) == 0 && sq) atomicAdd(sumsq, sq);
 }
 
 // single block: exclusive scan of the per-tile sums; totals to tmp[nblk]
@@ -219,13 +217,13 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, in
 }
 
 __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ pts4, const int* __restrict__ cell_of,
-                                                    const int* __restrict__ cell_start, int* __restrict__ cell_fill,
+                                                    const int* __restrict__ cell_start, const int* __restrict__ rank_of,
                                                     int64_t n, float4* __restrict__ sorted4,
                                                     const double4* __restrict__ pts4d, double4* __restrict__ sorted4d) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int c = cell_of[i];
-    int pos = cell_start[c] + atomicAdd(&cell_fill[c], 1);
+    int pos = cell_start[c] + rank_of[i];
     sorted4[pos] = pts4[i];
     if (pts4d) sorted4d[pos] = pts4d[i];
 }
@@ -304,6 +302,10 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     a = fmin(a, emax * 1.0001 + 1e-30);
 
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
+    const int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
+    ctx->items_q = items_q;
+    int nblk = 0;
     pct_grid g = {};
     double a_prev = 0, m_prev = 0;
     int iters = 0;
@@ -319,9 +321,12 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_HIP(ctx, hipMemsetAsync(ctx->cell_cnt.p, 0, (size_t)(g.ncell + 1) * sizeof(int), ctx->stream));
         PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 16, ctx->stream));
         hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, n, g, (int*)ctx->cell_of.p, (int*)ctx->cell_cnt.p);
-        hipLaunchKernelGGL(k_occupancy, dim3(grid_1d(n, kBlock * 4, 1024)), dim3(kBlock), 0, ctx->stream,
-                           (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p, n,
+                           (const float4*)ctx->pts4.p, n, g, (int*)ctx->cell_of.p, (int*)ctx->cell_fill.p,
+                           (int*)ctx->cell_cnt.p);
+        nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
+        PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int2)));
+        hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+                           (const int*)ctx->cell_cnt.p, g.ncell, items_q, (int2*)ctx->scan_tmp.p,
                            (unsigned long long*)ctx->red.p);
         PCT_HIP(ctx, hipGetLastError());
         unsigned long long s2 = 0;
@@ -351,14 +356,8 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->tm.cells = g.ncell;
     ctx->tm.cell_size = g.cell;
 
-    // exclusive scan + ordered occupied-cell list
-    const int nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
-    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int2)));
-    const int items_q = ctx->items_q > 0 ? ctx->items_q : 12;
-    ctx->items_q = items_q;
+    // rest of the exclusive scan + ordered work-item list
     PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n < g.ncell ? n : g.ncell) + (size_t)n / items_q + 16) * sizeof(int2)));
-    hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                       (const int*)ctx->cell_cnt.p, g.ncell, items_q, (int2*)ctx->scan_tmp.p);
     hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int2*)ctx->scan_tmp.p, nblk);
     hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                        (int*)ctx->cell_cnt.p, g.ncell, items_q, (const int2*)ctx->scan_tmp.p, (int2*)ctx->occ.p);
@@ -367,13 +366,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     PCT_HIP(ctx, hipMemcpyAsync(&tot, (int2*)ctx->scan_tmp.p + nblk, sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
 
     // counting-sort scatter
-    PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)g.ncell * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->cell_fill.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
     hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                        (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
-                       (int*)ctx->cell_fill.p, n, (float4*)ctx->sorted4.p,
+                       (const int*)ctx->cell_fill.p, n, (float4*)ctx->sorted4.p,
                        ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
                        ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
     PCT_HIP(ctx, hipGetLastError());
