@@ -117,6 +117,13 @@ int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end,
 int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t rows,
                                      float* K, float* H, float* H2);
 
+/* explicit_quadratic_neighbor_study (pct:732-800), the numeric part: for every sample row s and every
+ * neighbour count n in [n_lo, n_hi], the Gaussian curvature of the quadric fitted to the point itself plus
+ * its n nearest neighbours (pct:759-761).  Needs a resident plain k-NN table with k >= n_hi.
+ * K_out: (n_samples, n_hi - n_lo + 1) float32.  The bisection over n stays on the host. */
+int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int64_t n_samples,
+                                   int32_t n_lo, int32_t n_hi, float* K_out);
+
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
 /* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pct_curvature": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
     "pct_get_fit": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p, _f32p]),
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
+    "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
     "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
     "pct_device_free": (C.c_int, [_p, _p]),
@@ -227,6 +228,13 @@ class Handle:
         self._check(self._lib.pct_curvatures_from_coefficients(self._h, _ptr(c, _f32p), len(c), _ptr(k, _f32p),
                                                                _ptr(h, _f32p), _ptr(h2, _f32p)))
         return k, h, h2
+
+    def neighbor_study_curvatures(self, sample_rows, n_lo, n_hi):
+        rows = np.ascontiguousarray(sample_rows, dtype=np.int64)
+        out = np.empty((len(rows), int(n_hi) - int(n_lo) + 1), np.float32)
+        self._check(self._lib.pct_neighbor_study_curvatures(self._h, _ptr(rows, _i64p), len(rows), int(n_lo), int(n_hi),
+                                                           _ptr(out, _f32p)))
+        return out
 
     def timings(self):
         t = Timings()

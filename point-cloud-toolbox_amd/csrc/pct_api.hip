@@ -85,7 +85,7 @@ void pct_destroy(pct_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
-                      &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
+                      &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->pos_of, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
                       &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
     for (pct_buf* b : all) release(b);
@@ -322,7 +322,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     PCT_TRY(pct_launch_fit_rows(ctx, (const int*)ctx->stage_a.p, count ? (const int*)ctx->stage_c.p : nullptr,
                                 query ? (const int64_t*)ctx->stage_d.p : nullptr, rows, k, pitch, (float*)ctx->coefs.p,
-                                (float*)ctx->K.p, (float*)ctx->H.p, (float*)ctx->H2.p));
+                                (float*)ctx->K.p, (float*)ctx->H.p, (float*)ctx->H2.p, false, false));
     PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
@@ -359,6 +359,51 @@ int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t r
     if (K) PCT_HIP(ctx, hipMemcpyAsync(K, d_out, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (H) PCT_HIP(ctx, hipMemcpyAsync(H, d_out + rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (H2) PCT_HIP(ctx, hipMemcpyAsync(H2, d_out + 2 * rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int64_t n_samples, int32_t n_lo, int32_t n_hi,
+                                   float* K_out) {
+    PCT_TRY(begin_call(ctx));
+    if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "plant the neighbour table first (pct_knn)");
+    if (!sample_rows || !K_out || n_samples <= 0 || n_lo < 1 || n_hi < n_lo) return pct_fail(ctx, PCT_ERR_INVALID, "bad study arguments");
+    if (n_hi > ctx->k) return pct_fail(ctx, PCT_ERR_INVALID, "the study needs %d neighbours per point, the table holds %d", n_hi, ctx->k);
+    if (ctx->eps > 0) return pct_fail(ctx, PCT_ERR_INVALID, "the study needs a plain k-NN table (no eps bound)");
+    const int nn = n_hi - n_lo + 1;
+    const int64_t rows = n_samples * nn;
+    if (rows > (int64_t)1 << 30) return pct_fail(ctx, PCT_ERR_INVALID, "study too large");
+    // sample rows -> positions in the order the table is indexed by
+    int* h_pos = (int*)malloc((size_t)n_samples * sizeof(int));
+    if (!h_pos) return pct_fail(ctx, PCT_ERR_OOM, "host allocation failed");
+    for (int64_t i = 0; i < n_samples; ++i) {
+        if (sample_rows[i] < ctx->q_begin || sample_rows[i] >= ctx->q_end) {
+            free(h_pos);
+            return pct_fail(ctx, PCT_ERR_INVALID, "sample row %lld outside the owned range", (long long)sample_rows[i]);
+        }
+        h_pos[i] = (int)sample_rows[i];
+    }
+    const int32_t pitch = (n_hi + 1 + 3) & ~3;
+    int st = pct_reserve(ctx, &ctx->stage_c, (size_t)n_samples * sizeof(int));
+    if (st == PCT_OK) st = pct_reserve(ctx, &ctx->stage_a, (size_t)rows * pitch * sizeof(int));
+    if (st == PCT_OK) st = pct_reserve(ctx, &ctx->stage_b, (size_t)rows * (sizeof(int) + 9 * sizeof(float)));
+    if (st == PCT_OK) st = pct_reserve(ctx, &ctx->stage_d, (size_t)rows * sizeof(int64_t));
+    if (st != PCT_OK) { free(h_pos); return st; }
+    hipError_t e = hipMemcpyAsync(ctx->stage_c.p, h_pos, (size_t)n_samples * sizeof(int), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    free(h_pos);
+    if (e != hipSuccess) return pct_fail(ctx, PCT_ERR_HIP, "sample upload failed: %s", hipGetErrorString(e));
+    int* d_spos = (int*)ctx->stage_c.p;
+    if (ctx->knn_sorted_space) {      // public row -> sorted position, on the device
+        PCT_TRY(pct_launch_gather_int(ctx, (const int*)ctx->pos_of.p, d_spos, n_samples));
+    }
+    int* d_cnt = (int*)ctx->stage_b.p;
+    float* d_out = (float*)(d_cnt + rows);            // coefs (rows,6), K, H, H2
+    PCT_TRY(pct_launch_prefix_rows(ctx, d_spos, n_samples, n_lo, n_hi, (int*)ctx->stage_a.p, pitch, d_cnt,
+                                   (int64_t*)ctx->stage_d.p));
+    PCT_TRY(pct_launch_fit_rows(ctx, (const int*)ctx->stage_a.p, d_cnt, (const int64_t*)ctx->stage_d.p, rows, n_hi + 1, pitch,
+                                d_out, d_out + rows * 6, d_out + rows * 7, d_out + rows * 8, ctx->knn_sorted_space, true));
+    PCT_HIP(ctx, hipMemcpyAsync(K_out, d_out + rows * 6, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCT_OK;
 }

@@ -100,6 +100,65 @@ __device__ __forceinline__ void load_centred(const FitArgs& a, int id, double qx
     }
 }
 
+// Tangent-plane rotation from the moment sums of one centred neighbourhood:
+// covariance about the neighbour mean with ddof=1 (pct:277), cyclic Jacobi,
+// normal = eigenvector of the smallest eigenvalue (== Vt[-1], pct:283), sign
+// flip by the far-minus-near reference vector (pct:286-297), Rodrigues rotation
+// taking the normal to +z (pct:300-312).  rot = {r00,r01,r02, r10,.., r22}.
+template <bool F64>
+__device__ __forceinline__ void plane_rotation(int m, double sx, double sy, double sz, double sxx, double sxy, double sxz,
+                                               double syy, double syz, double szz, double fx, double fy, double fz,
+                                               double lx, double ly, double lz, double (&rot)[9]) {
+    const double inv_m = 1.0 / (double)m, inv_m1 = 1.0 / (double)(m - 1);
+    const double mx = sx * inv_m, my_ = sy * inv_m, mz = sz * inv_m;
+    double a00 = (sxx - sx * mx) * inv_m1, a01 = (sxy - sx * my_) * inv_m1, a02 = (sxz - sx * mz) * inv_m1;
+    double a11 = (syy - sy * my_) * inv_m1, a12 = (syz - sy * mz) * inv_m1, a22 = (szz - sz * mz) * inv_m1;
+
+    // ---- cyclic Jacobi on the symmetric 3x3 --------------------------------
+    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // v[row][col]
+#pragma unroll 1
+    for (int sweep = 0; sweep < 8; ++sweep) {
+        // off-diagonal mass below 1e-22 of the trace: eigenvectors are converged far beyond fp64 round-off
+        const double off = fabs(a01) + fabs(a02) + fabs(a12);
+        if (off <= 1e-22 * (fabs(a00) + fabs(a11) + fabs(a22))) break;
+        JACOBI_ROT(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21);   // (p,q)=(0,1), r=2
+        JACOBI_ROT(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);   // (0,2), r=1
+        JACOBI_ROT(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);   // (1,2), r=0
+    }
+    double n0, n1, n2;
+    if (a00 <= a11 && a00 <= a22) { n0 = v00; n1 = v10; n2 = v20; }
+    else if (a11 <= a22)          { n0 = v01; n1 = v11; n2 = v21; }
+    else                          { n0 = v02; n1 = v12; n2 = v22; }
+
+    // ---- orientation: far-minus-near neighbour (pct:286-297) ---------------
+    double rx, ry, rz;
+    if (F64) { rx = lx - fx; ry = ly - fy; rz = lz - fz; }
+    else     { rx = (double)((float)lx - (float)fx); ry = (double)((float)ly - (float)fy); rz = (double)((float)lz - (float)fz); }
+    {
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        const double rn = sqrt((rx * rx + ry * ry) + rz * rz);
+        const double dot = ((n0 / nn) * (rx / rn) + (n1 / nn) * (ry / rn)) + (n2 / nn) * (rz / rn);
+        if (dot < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
+    }
+    // ---- Rodrigues rotation taking the normal to +z (pct:300-312) -----------
+    double r00 = 1, r01 = 0, r02 = 0, r10 = 0, r11 = 1, r12 = 0, r20 = 0, r21 = 0, r22 = 1;
+    {
+        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
+        const double ax = n0 / nn, ay = n1 / nn, az = n2 / nn;
+        const double v0 = ay, v1 = -ax;                    // a x (0,0,1)
+        const double c = az;
+        const double s = sqrt(v0 * v0 + v1 * v1);
+        if (s != 0.0) {
+            const double f = (1.0 - c) / (s * s);
+            r00 = 1.0 + (-(v1 * v1)) * f;  r01 = (v1 * v0) * f;            r02 = v1;
+            r10 = (v0 * v1) * f;           r11 = 1.0 + (-(v0 * v0)) * f;   r12 = -v0;
+            r20 = -v1;                     r21 = v0;                       r22 = 1.0 + (-(v1 * v1) + -(v0 * v0)) * f;
+        }
+    }
+
+    rot[0] = r00; rot[1] = r01; rot[2] = r02; rot[3] = r10; rot[4] = r11; rot[5] = r12; rot[6] = r20; rot[7] = r21; rot[8] = r22;
+}
+
 template <bool F64>
 __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     extern __shared__ int s_idx[];   // 64 rows x kp
@@ -169,52 +228,9 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         }
     }
 #undef PASS1_ACC
-    const double inv_m = 1.0 / (double)m, inv_m1 = 1.0 / (double)(m - 1);
-    const double mx = sx * inv_m, my_ = sy * inv_m, mz = sz * inv_m;
-    double a00 = (sxx - sx * mx) * inv_m1, a01 = (sxy - sx * my_) * inv_m1, a02 = (sxz - sx * mz) * inv_m1;
-    double a11 = (syy - sy * my_) * inv_m1, a12 = (syz - sy * mz) * inv_m1, a22 = (szz - sz * mz) * inv_m1;
-
-    // ---- cyclic Jacobi on the symmetric 3x3 --------------------------------
-    double v00 = 1, v01 = 0, v02 = 0, v10 = 0, v11 = 1, v12 = 0, v20 = 0, v21 = 0, v22 = 1;   // v[row][col]
-#pragma unroll 1
-    for (int sweep = 0; sweep < 8; ++sweep) {
-        // off-diagonal mass below 1e-22 of the trace: eigenvectors are converged far beyond fp64 round-off
-        const double off = fabs(a01) + fabs(a02) + fabs(a12);
-        if (off <= 1e-22 * (fabs(a00) + fabs(a11) + fabs(a22))) break;
-        JACOBI_ROT(a00, a11, a01, a02, a12, v00, v10, v20, v01, v11, v21);   // (p,q)=(0,1), r=2
-        JACOBI_ROT(a00, a22, a02, a01, a12, v00, v10, v20, v02, v12, v22);   // (0,2), r=1
-        JACOBI_ROT(a11, a22, a12, a01, a02, v01, v11, v21, v02, v12, v22);   // (1,2), r=0
-    }
-    double n0, n1, n2;
-    if (a00 <= a11 && a00 <= a22) { n0 = v00; n1 = v10; n2 = v20; }
-    else if (a11 <= a22)          { n0 = v01; n1 = v11; n2 = v21; }
-    else                          { n0 = v02; n1 = v12; n2 = v22; }
-
-    // ---- orientation: far-minus-near neighbour (pct:286-297) ---------------
-    double rx, ry, rz;
-    if (F64) { rx = lx - fx; ry = ly - fy; rz = lz - fz; }
-    else     { rx = (double)((float)lx - (float)fx); ry = (double)((float)ly - (float)fy); rz = (double)((float)lz - (float)fz); }
-    {
-        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
-        const double rn = sqrt((rx * rx + ry * ry) + rz * rz);
-        const double dot = ((n0 / nn) * (rx / rn) + (n1 / nn) * (ry / rn)) + (n2 / nn) * (rz / rn);
-        if (dot < 0) { n0 = -n0; n1 = -n1; n2 = -n2; }
-    }
-    // ---- Rodrigues rotation taking the normal to +z (pct:300-312) -----------
-    double r00 = 1, r01 = 0, r02 = 0, r10 = 0, r11 = 1, r12 = 0, r20 = 0, r21 = 0, r22 = 1;
-    {
-        const double nn = sqrt((n0 * n0 + n1 * n1) + n2 * n2);
-        const double ax = n0 / nn, ay = n1 / nn, az = n2 / nn;
-        const double v0 = ay, v1 = -ax;                    // a x (0,0,1)
-        const double c = az;
-        const double s = sqrt(v0 * v0 + v1 * v1);
-        if (s != 0.0) {
-            const double f = (1.0 - c) / (s * s);
-            r00 = 1.0 + (-(v1 * v1)) * f;  r01 = (v1 * v0) * f;            r02 = v1;
-            r10 = (v0 * v1) * f;           r11 = 1.0 + (-(v0 * v0)) * f;   r12 = -v0;
-            r20 = -v1;                     r21 = v0;                       r22 = 1.0 + (-(v1 * v1) + -(v0 * v0)) * f;
-        }
-    }
+    double rot[9];
+    plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
+    const double r00 = rot[0], r01 = rot[1], r02 = rot[2], r10 = rot[3], r11 = rot[4], r12 = rot[5], r20 = rot[6], r21 = rot[7], r22 = rot[8];
 
     // ---- pass 2: float32 design rows -> scaled fp64 normal equations --------
     int e2 = 0;
@@ -321,6 +337,133 @@ __global__ __launch_bounds__(256) void k_curv(const float* __restrict__ coefs, i
     H2[r] = Kh * Kh;
 }
 
+// ---------------------------------------------------------------------------
+// Under-determined neighbourhoods (2 <= m <= 5 points): numpy.linalg.lstsq
+// (pct:359) returns the minimum-norm solution of the float32 design system.
+// Reached only by explicit_quadratic_neighbor_study (pct:759: n+1 points with
+// n >= 3).  Householder QR of X^T (6 x m) in registers, c = Q R^-T z, no column
+// scaling (scaling would change the norm that is minimised).
+// ---------------------------------------------------------------------------
+template <bool F64>
+__global__ __launch_bounds__(64) void k_fit_minnorm(FitArgs a) {
+    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= a.rows) return;
+    const int m = a.cnt[row];
+    if (m >= 6) return;                       // handled by k_fit
+    const int64_t qid = a.row_query ? a.row_query[row] : row;
+    const float4 qp = a.pts[qid];
+    double qx = qp.x, qy = qp.y, qz = qp.z;
+    if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
+    const int* my = a.table + row * a.pitch;
+    const float nanf_ = __int_as_float(0x7fc00000);
+    float* co = a.coefs + row * 6;
+    if (m < 2) {
+        for (int j = 0; j < 6; ++j) co[j] = nanf_;
+        a.K[row] = nanf_; a.H[row] = nanf_; a.H2[row] = nanf_;
+        return;
+    }
+    double px[5], py[5], pz[5];
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        px[j] = py[j] = pz[j] = 0;
+        if (j < m) {
+            load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, px[j], py[j], pz[j]);
+            const double x = px[j], y = py[j], z = pz[j];
+            if (j == 0) { fx = x; fy = y; fz = z; }
+            lx = x; ly = y; lz = z;
+            sx += x; sy += y; sz += z;
+            sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
+            syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
+        }
+    }
+    double rot[9];
+    plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
+    // A = X^T: column j = design row of neighbour j (float32 entries, pct:358)
+    double A[5][6], zv[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const float pa = (float)((rot[0] * px[j] + rot[1] * py[j]) + rot[2] * pz[j]);
+        const float pb = (float)((rot[3] * px[j] + rot[4] * py[j]) + rot[5] * pz[j]);
+        const float pc = (float)((rot[6] * px[j] + rot[7] * py[j]) + rot[8] * pz[j]);
+        const bool v = j < m;
+        A[j][0] = v ? (double)(pa * pa) : 0.0; A[j][1] = v ? (double)(pb * pb) : 0.0; A[j][2] = v ? (double)(pa * pb) : 0.0;
+        A[j][3] = v ? (double)pa : 0.0;        A[j][4] = v ? (double)pb : 0.0;        A[j][5] = v ? 1.0 : 0.0;
+        zv[j] = v ? (double)pc : 0.0;
+    }
+    // Householder QR, column by column; reflector j acts on components j..5
+    double beta[5], rdiag[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        double nrm2 = 0;
+#pragma unroll
+        for (int i = j; i < 6; ++i) nrm2 = fma(A[j][i], A[j][i], nrm2);
+        const double nrm = sqrt(nrm2);
+        const double alpha = A[j][j] > 0 ? -nrm : nrm;
+        rdiag[j] = alpha;
+        A[j][j] -= alpha;                                   // v = x - alpha e1 (stored in place)
+        double vv = 0;
+#pragma unroll
+        for (int i = j; i < 6; ++i) vv = fma(A[j][i], A[j][i], vv);
+        beta[j] = vv > 0 ? 2.0 / vv : 0.0;
+#pragma unroll
+        for (int c = j + 1; c < 5; ++c) {
+            double dotp = 0;
+#pragma unroll
+            for (int i = j; i < 6; ++i) dotp = fma(A[j][i], A[c][i], dotp);
+            const double f = beta[j] * dotp;
+#pragma unroll
+            for (int i = j; i < 6; ++i) A[c][i] -= f * A[j][i];
+        }
+    }
+    // R^T y = z  (R upper triangular: R[p][c] = A[c][p] for p < c, diagonal rdiag)
+    double y[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+        double sacc = zv[c];
+#pragma unroll
+        for (int p2 = 0; p2 < c; ++p2) sacc -= A[c][p2] * y[p2];
+        y[c] = c < m ? sacc / rdiag[c] : 0.0;
+    }
+    // c = Q [y; 0]: reflectors in reverse order
+#pragma unroll
+    for (int j = 4; j >= 0; --j) {
+        if (j < m) {
+            double dotp = 0;
+#pragma unroll
+            for (int i = j; i < 6; ++i) dotp = fma(A[j][i], y[i], dotp);
+            const double f = beta[j] * dotp;
+#pragma unroll
+            for (int i = j; i < 6; ++i) y[i] -= f * A[j][i];
+        }
+    }
+    const float Af = (float)y[0], Bf = (float)y[1], Cf = (float)y[2], Df = (float)y[3], Ef = (float)y[4];
+    co[0] = Af; co[1] = Bf; co[2] = Cf; co[3] = Df; co[4] = Ef; co[5] = (float)y[5];
+    float Kg, Kh;
+    monge_curvatures(Af, Bf, Cf, Df, Ef, Kg, Kh);
+    a.K[row] = Kg;
+    a.H[row] = Kh;
+    a.H2[row] = Kh * Kh;
+}
+
+// explicit_quadratic_neighbor_study (pct:756-761): row (s, n) = the sample point itself followed by its n nearest
+// neighbours, n = n_lo .. n_hi, taken from the resident neighbour table
+__global__ __launch_bounds__(256) void k_prefix_rows(const int* __restrict__ sample_pos, int64_t n_samples, int n_lo, int n_hi,
+                                                     const int* __restrict__ nbr_pos, int nbr_pitch,
+                                                     int* __restrict__ table, int pitch, int* __restrict__ cnt,
+                                                     int64_t* __restrict__ row_query) {
+    const int nn = n_hi - n_lo + 1;
+    const int64_t row = blockIdx.x;
+    if (row >= n_samples * nn) return;
+    const int64_t s = row / nn;
+    const int n = n_lo + (int)(row - s * nn);
+    const int q = sample_pos[s];
+    int* dst = table + row * pitch;
+    for (int j = threadIdx.x; j <= n; j += 256) dst[j] = j == 0 ? q : nbr_pos[(int64_t)q * nbr_pitch + (j - 1)];
+    if (threadIdx.x == 0) { cnt[row] = n + 1; row_query[row] = q; }
+}
+
 int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     FitArgs a = a0;
     a.kp = a.k | 1;
@@ -366,12 +509,13 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     return launch(ctx, a, ctx->has_f64);
 }
 
-// fit from caller-supplied neighbour rows (public indices), outputs row-aligned
+// fit from explicit neighbour rows, outputs row-aligned.  sorted_space: ids refer to the cell-sorted arrays.
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query,
-                        int64_t rows, int32_t k, int32_t pitch, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
+                        int64_t rows, int32_t k, int32_t pitch, float* d_coefs, float* d_K, float* d_H, float* d_H2,
+                        bool sorted_space, bool minnorm_pass) {
     FitArgs a = {};
-    a.pts = (const float4*)ctx->pts4.p;
-    a.ptsd = ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr;
+    a.pts = (const float4*)(sorted_space ? ctx->sorted4.p : ctx->pts4.p);
+    a.ptsd = ctx->has_f64 ? (const double4*)(sorted_space ? ctx->sorted4d.p : ctx->pts4d.p) : nullptr;
     a.table = d_idx;
     a.cnt = d_cnt;
     a.row_query = d_query;
@@ -386,7 +530,25 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
     a.K = d_K;
     a.H = d_H;
     a.H2 = d_H2;
-    return launch(ctx, a, ctx->has_f64);
+    PCT_TRY(launch(ctx, a, ctx->has_f64));
+    if (minnorm_pass && d_cnt) {              // rows with fewer than 6 points: minimum-norm lstsq (overwrites the NaNs)
+        const int blocks = (int)((rows + 63) / 64);
+        if (ctx->has_f64)
+            hipLaunchKernelGGL(k_fit_minnorm<true>, dim3(blocks), dim3(64), 0, ctx->stream, a);
+        else
+            hipLaunchKernelGGL(k_fit_minnorm<false>, dim3(blocks), dim3(64), 0, ctx->stream, a);
+        PCT_HIP(ctx, hipGetLastError());
+    }
+    return PCT_OK;
+}
+
+int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samples, int n_lo, int n_hi, int* d_table,
+                           int pitch, int* d_cnt, int64_t* d_row_query) {
+    const int64_t rows = n_samples * (n_hi - n_lo + 1);
+    hipLaunchKernelGGL(k_prefix_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_sample_pos, n_samples, n_lo, n_hi,
+                       (const int*)ctx->nbr_pos.p, ctx->nbr_pitch, d_table, pitch, d_cnt, d_row_query);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
 }
 
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2) {

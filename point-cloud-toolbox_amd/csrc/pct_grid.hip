@@ -218,14 +218,20 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, in
 
 __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ pts4, const int* __restrict__ cell_of,
                                                     const int* __restrict__ cell_start, const int* __restrict__ rank_of,
-                                                    int64_t n, float4* __restrict__ sorted4,
+                                                    int64_t n, float4* __restrict__ sorted4, int* __restrict__ pos_of,
                                                     const double4* __restrict__ pts4d, double4* __restrict__ sorted4d) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     int c = cell_of[i];
     int pos = cell_start[c] + rank_of[i];
     sorted4[pos] = pts4[i];
+    pos_of[i] = pos;
     if (pts4d) sorted4d[pos] = pts4d[i];
+}
+
+__global__ __launch_bounds__(256) void k_gather_int(const int* __restrict__ map, int* __restrict__ io, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) io[i] = map[io[i]];
 }
 
 int grid_1d(int64_t n, int per_block, int cap) {
@@ -367,10 +373,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
 
     // counting-sort scatter
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
+    PCT_TRY(pct_reserve(ctx, &ctx->pos_of, (size_t)n * sizeof(int)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                        (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
-                       (const int*)ctx->cell_fill.p, n, (float4*)ctx->sorted4.p,
+                       (const int*)ctx->cell_fill.p, n, (float4*)ctx->sorted4.p, (int*)ctx->pos_of.p,
                        ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
                        ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
     PCT_HIP(ctx, hipGetLastError());
@@ -380,5 +387,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->n_occ = tot.y;
     ctx->tm.occupied_cells = tot.y;
     ctx->grid_valid = true;
+    return PCT_OK;
+}
+
+int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n) {
+    hipLaunchKernelGGL(k_gather_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_map, d_inout, n);
+    PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

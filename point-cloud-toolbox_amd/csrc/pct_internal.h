@@ -56,6 +56,7 @@ struct pct_ctx {
     int32_t items_q = 12;
     pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
     pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
+    pct_buf pos_of;     // int32 (n) sorted position of every public index
     pct_buf red;        // small reduction scratch
     int64_t n_occ = 0;
     bool grid_valid = false;
@@ -114,6 +115,9 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
 int pct_launch_fit_table(pct_ctx* ctx);
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt,
                         const int64_t* d_query, int64_t rows, int32_t k, int32_t pitch,
-                        float* d_coefs, float* d_K, float* d_H, float* d_H2);
+                        float* d_coefs, float* d_K, float* d_H, float* d_H2, bool sorted_space, bool minnorm_pass);
+int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samples, int n_lo, int n_hi, int* d_table,
+                           int pitch, int* d_cnt, int64_t* d_row_query);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
+int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);

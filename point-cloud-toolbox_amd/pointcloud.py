@@ -182,6 +182,45 @@ class PointCloud:
         K, H = self.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
         return np.array(K), np.array(H)
 
+    # ----------------------------------------------------------------- A10
+    def explicit_quadratic_neighbor_study(self, tol=1e-7, sample_size=500, lower_bound=3, upper_bound=99):
+        """Neighbour count at which the Gaussian curvature stops changing (pct:732-800).
+
+        Same draw (``np.random.randint`` on the global generator, pct:753), same per-point bisection
+        (pct:772-789) and same return value ``int(mean) + 1`` (pct:800) as the reference.  The curvature
+        K(n) of "the point itself plus its n nearest neighbours" (pct:759-761) is evaluated on the GPU for
+        every n the bisection can ask for, from a k = upper_bound+1 neighbour table.
+        """
+        num_total = len(self.points)
+        sample_size = min(sample_size, num_total)
+        random_indexes = np.random.randint(0, num_total, sample_size)                  # pct:753
+        if sample_size == 0:
+            return 0                                                                   # pct:797-798
+        need = upper_bound + 1
+        h = self._ctx()
+        own = getattr(h, "k", 0) >= need and not self.eps and self._user_neighbors is None
+        if not own:      # keep the planted table untouched: a second context does the k=need sweep
+            h = _capi.Handle(self._device)
+            pts = np.asarray(self.points)
+            h.set_points(pts if pts.dtype == np.float64 else pts.astype(np.float32, copy=False))
+            h.knn(need)
+        try:
+            Kn = h.neighbor_study_curvatures(random_indexes, lower_bound, need)        # columns n = lower..upper+1
+        finally:
+            if not own:
+                h.close()
+        converged = []
+        for row in Kn:
+            lower, upper, best = lower_bound, upper_bound, None
+            while lower <= upper:                                                      # pct:778-786
+                mid = (lower + upper) // 2
+                if abs(row[mid + 1 - lower_bound] - row[mid - lower_bound]) < tol:
+                    best, upper = mid, mid - 1
+                else:
+                    lower = mid + 1
+            converged.append(upper if best is None else best)                          # pct:787-788
+        return int(np.mean(converged)) + 1                                             # pct:800
+
     # fused entry: k-NN -> fit -> curvature with nothing but K/H leaving the GPU
     def compute_curvature_fused(self, k_neighbors, eps=None, algorithm="auto"):
         self.k_neighbors = k_neighbors

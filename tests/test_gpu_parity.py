@@ -324,3 +324,52 @@ def test_k_neighbors_overwritten_by_plant(gpu):
     pc = gpu["PointCloud"](points=pts, normals=np.zeros((3000, 0)), k_neighbors=20)
     pc.plant_kdtree(12)
     assert pc.k_neighbors == 12 and pc.neighbor_indices.shape == (3000, 12)          # pct:71
+
+
+# ------------------------------------------------- next row N1: neighbour study
+def test_neighbor_study_matches_reference_golden(gpu, golden):
+    """explicit_quadratic_neighbor_study (pct:732-800) with the reference's own seeded draw (G8)."""
+    g2, g8 = golden("g2_torus4k_k50.npz"), golden("g8_neighbor_study.npz")
+    pc = gpu["PointCloud"](points=g2["points"], normals=np.zeros((4000, 0)))
+    pc.plant_kdtree(50)
+    np.random.seed(0)
+    res = pc.explicit_quadratic_neighbor_study(sample_size=60)
+    assert res == int(g8["result"])
+    assert pc.k_neighbors == 50 and pc.neighbor_indices.shape == (4000, 50)       # planted table untouched
+    pc.plant_kdtree(100)                                                          # validate_shape's order (utils.py:484-487)
+    np.random.seed(0)
+    assert pc.explicit_quadratic_neighbor_study(sample_size=60) == int(g8["result"])
+
+
+def test_neighbor_study_curvature_table_vs_oracle(gpu):
+    """K(n) for every n, including the under-determined n+1 < 6 prefixes (minimum-norm lstsq, pct:359)."""
+    rng = np.random.default_rng(3)
+    xy = rng.uniform(-1, 1, size=(3000, 2))
+    pts = np.column_stack([xy, 0.15 * xy[:, 0] ** 2 - 0.1 * xy[:, 1] ** 2 + 0.05 * xy[:, 0] * xy[:, 1]]).astype(np.float32)
+    h = gpu["capi"].Handle(0)
+    h.set_points(pts)
+    h.knn(40, 0.0, gpu["capi"].KNN_GRID)
+    rows = np.array([5, 77, 1500, 2999])
+    Kn = h.neighbor_study_curvatures(rows, 3, 40)
+    h.close()
+    from scipy.spatial import cKDTree
+    tree = cKDTree(pts)
+    for r, i in enumerate(rows):
+        for n in (3, 4, 5, 6, 7, 20, 40):
+            nb = pts[tree.query(pts[i], n + 1)[1]]
+            ref = oracle.quadric_curvatures(oracle.quadric_fit(oracle.plane_align(nb - pts[i])))[0]
+            got = Kn[r, n - 3]
+            assert abs(got - ref) <= 1e-5 * max(abs(ref), 1e-2), (i, n, got, ref)
+
+
+def test_neighbor_study_on_a_plane_converges_low(gpu):
+    """Exact plane: |K(n+1)-K(n)| < tol everywhere, the bisection walks down to the lower bound."""
+    rng = np.random.default_rng(9)
+    pts = np.column_stack([rng.uniform(-1, 1, size=(5000, 2)), np.zeros(5000)]).astype(np.float32)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((5000, 0)))
+    np.random.seed(1)
+    res = pc.explicit_quadratic_neighbor_study(sample_size=40)
+    np.random.seed(1)
+    sample = np.random.randint(0, 5000, 40)
+    ref, _ = oracle.neighbor_study(pts, sample)
+    assert res == ref
