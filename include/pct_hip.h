@@ -93,6 +93,10 @@ int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo);
 int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                       int32_t* idx, float* dist, int32_t* count);
 
+/* Same for an explicit list of cloud rows (sampled checks on clouds whose full table is tens of GB). */
+int pct_get_neighbor_rows(pct_ctx* ctx, const int64_t* rows, int64_t n_rows,
+                          int32_t* idx, float* dist, int32_t* count);
+
 /* ---- fit_explicit_quadratic_surfaces_to_neighborhoods (pct:635-647)
  *      + calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points
  *        (pct:657-674) ---------------------------------------------------- */

@@ -62,6 +62,7 @@ SIGNATURES = {
     "pct_set_stats": (C.c_int, [_p, C.c_int32]),
     "pct_knn": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
     "pct_get_neighbors": (C.c_int, [_p, C.c_int64, C.c_int64, _i32p, _f32p, _i32p]),
+    "pct_get_neighbor_rows": (C.c_int, [_p, _i64p, C.c_int64, _i32p, _f32p, _i32p]),
     "pct_fit": (C.c_int, [_p]),
     "pct_fit_indices": (C.c_int, [_p, _i32p, _i32p, _i64p, C.c_int64, C.c_int32]),
     "pct_curvature": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
@@ -198,6 +199,15 @@ class Handle:
         cnt = np.empty(rows, np.int32) if want_count else None
         self._check(self._lib.pct_get_neighbors(self._h, int(begin), int(end), _ptr(idx, _i32p),
                                                 _ptr(dist, _f32p), _ptr(cnt, _i32p)))
+        return idx, dist, cnt
+
+    def get_neighbor_rows(self, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        idx = np.empty((len(rows), self.k), np.int32)
+        dist = np.empty((len(rows), self.k), np.float32)
+        cnt = np.empty(len(rows), np.int32)
+        self._check(self._lib.pct_get_neighbor_rows(self._h, _ptr(rows, _i64p), len(rows), _ptr(idx, _i32p),
+                                                   _ptr(dist, _f32p), _ptr(cnt, _i32p)))
         return idx, dist, cnt
 
     def fit_indices(self, idx, count=None, query=None):

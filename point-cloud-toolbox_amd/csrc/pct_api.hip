@@ -282,6 +282,28 @@ int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_t* idx, fl
     return PCT_OK;
 }
 
+int pct_get_neighbor_rows(pct_ctx* ctx, const int64_t* rows, int64_t n_rows, int32_t* idx, float* dist, int32_t* count) {
+    PCT_TRY(begin_call(ctx));
+    if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "no neighbour table");
+    if (!rows || n_rows <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "bad row list");
+    for (int64_t i = 0; i < n_rows; ++i)
+        if (rows[i] < ctx->q_begin || rows[i] >= ctx->q_end)
+            return pct_fail(ctx, PCT_ERR_INVALID, "row %lld outside the owned range", (long long)rows[i]);
+    const size_t cells = (size_t)n_rows * ctx->k;
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_d, (size_t)n_rows * sizeof(int64_t)));
+    if (idx) PCT_TRY(pct_reserve(ctx, &ctx->stage_a, cells * sizeof(int)));
+    if (dist) PCT_TRY(pct_reserve(ctx, &ctx->stage_b, cells * sizeof(float)));
+    if (count) PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)n_rows * sizeof(int)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_d.p, rows, (size_t)n_rows * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_launch_export_rows(ctx, (const int64_t*)ctx->stage_d.p, n_rows, idx ? (int*)ctx->stage_a.p : nullptr,
+                                   dist ? (float*)ctx->stage_b.p : nullptr, count ? (int*)ctx->stage_c.p : nullptr));
+    if (idx) PCT_HIP(ctx, hipMemcpyAsync(idx, ctx->stage_a.p, cells * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    if (dist) PCT_HIP(ctx, hipMemcpyAsync(dist, ctx->stage_b.p, cells * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (count) PCT_HIP(ctx, hipMemcpyAsync(count, ctx->stage_c.p, (size_t)n_rows * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
 int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k) {
     PCT_TRY(begin_call(ctx));
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");

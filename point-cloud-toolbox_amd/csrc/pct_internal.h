@@ -121,3 +121,4 @@ int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samp
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);
+int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt);

@@ -791,6 +791,23 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
     if (cnt_out && j == 0) cnt_out[pub - begin] = nbr_cnt ? nbr_cnt[row] : k;
 }
 
+// the same for an explicit list of public rows (one block per listed row)
+__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ pos_of,
+                                                     const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
+                                                     const int* __restrict__ nbr_cnt, int64_t n, int k, int pitch,
+                                                     const int64_t* __restrict__ rows, int* __restrict__ idx_out,
+                                                     float* __restrict__ dist_out, int* __restrict__ cnt_out) {
+    const int64_t r = blockIdx.x;
+    const int64_t pub = rows[r];
+    const int64_t row = pos_of ? pos_of[pub] : pub;
+    for (int j = threadIdx.x; j < k; j += 128) {
+        const int pos = nbr_pos[row * pitch + j];
+        if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
+        if (dist_out) dist_out[r * k + j] = nbr_dist[row * pitch + j];
+    }
+    if (cnt_out && threadIdx.x == 0) cnt_out[r] = nbr_cnt ? nbr_cnt[row] : k;
+}
+
 // lane_xor<S>() against the generic shuffle, every S (hardware self-test)
 __global__ __launch_bounds__(64) void k_selftest(int* fails) {
     const int lane = lane_id();
@@ -897,6 +914,17 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream, pts, (const int*)ctx->nbr_pos.p,
                        (const float*)ctx->nbr_dist.p, ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n,
                        ctx->k, ctx->nbr_pitch, begin, end, d_idx, d_dist, d_cnt);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt) {
+    const bool sorted = ctx->knn_sorted_space;
+    hipLaunchKernelGGL(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
+                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->pos_of.p : nullptr,
+                       (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
+                       ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, ctx->k, ctx->nbr_pitch, d_rows, d_idx,
+                       d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

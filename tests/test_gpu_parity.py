@@ -326,6 +326,47 @@ def test_k_neighbors_overwritten_by_plant(gpu):
     assert pc.k_neighbors == 12 and pc.neighbor_indices.shape == (3000, 12)          # pct:71
 
 
+# ------------------------------------- BASELINE configs C4 / C5 at full size (sampled reference)
+def _sampled_check(h, g, n):
+    rows = g["rows"]
+    idx, dist, cnt = h.get_neighbor_rows(rows)
+    assert np.array_equal(cnt, g["count"])
+    assert np.array_equal(idx, g["idx"]) and np.array_equal(dist, g["dists"])
+    _, K, H, _ = h.get_fit(0, n, coefs=False, H2=False)
+    ok = g["count"] >= 6
+    assert ok.all()
+    assert_curvature(K[rows], H[rows], g["K"], g["H"])
+    return K, H
+
+
+def test_config_c4_egg_carton_5m(gpu, golden):
+    """BASELINE configs[3]: egg carton 5 M points k=50 (here on one GPU; the sharding changes no value)."""
+    g = golden("g7_egg5m_k50_sample.npz")
+    pts = gpu["shapes"].egg_carton_random(5_000_000, seed=1234)
+    h = gpu["capi"].Handle(0)
+    h.set_points(pts)
+    h.curvature(50)
+    _sampled_check(h, g, len(pts))
+    h.close()
+
+
+def test_config_c5_bunny_tiled_20m_eps(gpu, golden):
+    """BASELINE configs[4]: bunny.txt tiled to 20 022 479 points, k=80, hybrid eps=0.0062 query."""
+    import os
+    g = golden("g7_bunny20m_k80_eps_sample.npz")
+    bunny = np.load(os.path.join(os.path.dirname(__file__), "golden", "bunny_xyz_f32.npy"))
+    pts = gpu["shapes"].tile_cloud(bunny, 557)
+    assert len(pts) == 20_022_479
+    h = gpu["capi"].Handle(0)
+    h.set_points(pts)
+    h.curvature(80, float(g["eps"]))
+    K, H = _sampled_check(h, g, len(pts))
+    assert 30 <= g["count"].min() < 80 == g["count"].max()          # both branches of the hybrid query
+    t = h.timings()
+    print("C5 timings", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in t.items()})
+    h.close()
+
+
 # ------------------------------------------------- next row N1: neighbour study
 def test_neighbor_study_matches_reference_golden(gpu, golden):
     """explicit_quadratic_neighbor_study (pct:732-800) with the reference's own seeded draw (G8)."""
