@@ -85,7 +85,7 @@ void pct_destroy(pct_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
-                      &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->pos_of, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
+                      &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
                       &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
     for (pct_buf* b : all) release(b);
@@ -159,7 +159,7 @@ int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end) {
     if (begin < 0 || end > ctx->n || begin > end) return pct_fail(ctx, PCT_ERR_INVALID, "bad query range [%lld,%lld)", (long long)begin, (long long)end);
     ctx->q_begin = begin;
     ctx->q_end = end;
-    ctx->knn_valid = ctx->fit_valid = false;
+    ctx->knn_valid = ctx->fit_valid = ctx->grid_valid = false;   // the cell order depends on the owned range
     return PCT_OK;
 }
 
@@ -403,7 +403,7 @@ int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int6
             free(h_pos);
             return pct_fail(ctx, PCT_ERR_INVALID, "sample row %lld outside the owned range", (long long)sample_rows[i]);
         }
-        h_pos[i] = (int)sample_rows[i];
+        h_pos[i] = (int)(sample_rows[i] - (ctx->knn_sorted_space ? 0 : ctx->q_begin));   // exhaustive table: row = index - q_begin
     }
     const int32_t pitch = (n_hi + 1 + 3) & ~3;
     int st = pct_reserve(ctx, &ctx->stage_c, (size_t)n_samples * sizeof(int));
@@ -416,8 +416,8 @@ int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int6
     free(h_pos);
     if (e != hipSuccess) return pct_fail(ctx, PCT_ERR_HIP, "sample upload failed: %s", hipGetErrorString(e));
     int* d_spos = (int*)ctx->stage_c.p;
-    if (ctx->knn_sorted_space) {      // public row -> sorted position, on the device
-        PCT_TRY(pct_launch_gather_int(ctx, (const int*)ctx->pos_of.p, d_spos, n_samples));
+    if (ctx->knn_sorted_space) {      // public index -> neighbour-table row, on the device
+        PCT_TRY(pct_launch_gather_int(ctx, (const int*)ctx->row_of.p, d_spos, n_samples));
     }
     int* d_cnt = (int*)ctx->stage_b.p;
     float* d_out = (float*)(d_cnt + rows);            // coefs (rows,6), K, H, H2

@@ -35,7 +35,9 @@ struct FitArgs {
     const double4* ptsd;     // native fp64 coordinates (nullable), same order
     const int* table;        // (rows,k) neighbour ids into pts (-1 = missing)
     const int* cnt;          // (rows) valid neighbours per row (nullable -> k)
-    const int64_t* row_query;// (rows) query id into pts per row (nullable -> row)
+    const int64_t* row_query;// (rows) query id into pts per row (nullable -> row + row_offset)
+    const int* row_query32;  // the same as int32 (device-built lists); takes precedence
+    int64_t row_offset;
     int64_t rows;
     int k;
     int pitch;               // table row pitch in elements, multiple of 4
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
 
     const int64_t row = row0 + lane;
     if (row >= a.rows) return;
-    const int64_t qid = a.row_query ? a.row_query[row] : row;
+    const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
     const float4 qp = a.pts[qid];
     const int pub = __float_as_int(qp.w);
     if (!a.out_by_row && (pub < a.q_begin || pub >= a.q_end)) return;
@@ -350,7 +352,7 @@ __global__ __launch_bounds__(64) void k_fit_minnorm(FitArgs a) {
     if (row >= a.rows) return;
     const int m = a.cnt[row];
     if (m >= 6) return;                       // handled by k_fit
-    const int64_t qid = a.row_query ? a.row_query[row] : row;
+    const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
     const float4 qp = a.pts[qid];
     double qx = qp.x, qy = qp.y, qz = qp.z;
     if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
@@ -449,7 +451,8 @@ __global__ __launch_bounds__(64) void k_fit_minnorm(FitArgs a) {
 
 // explicit_quadratic_neighbor_study (pct:756-761): row (s, n) = the sample point itself followed by its n nearest
 // neighbours, n = n_lo .. n_hi, taken from the resident neighbour table
-__global__ __launch_bounds__(256) void k_prefix_rows(const int* __restrict__ sample_pos, int64_t n_samples, int n_lo, int n_hi,
+__global__ __launch_bounds__(256) void k_prefix_rows(const int* __restrict__ sample_row, const int* __restrict__ owned_pos,
+                                                     int q_begin, int64_t n_samples, int n_lo, int n_hi,
                                                      const int* __restrict__ nbr_pos, int nbr_pitch,
                                                      int* __restrict__ table, int pitch, int* __restrict__ cnt,
                                                      int64_t* __restrict__ row_query) {
@@ -458,9 +461,10 @@ __global__ __launch_bounds__(256) void k_prefix_rows(const int* __restrict__ sam
     if (row >= n_samples * nn) return;
     const int64_t s = row / nn;
     const int n = n_lo + (int)(row - s * nn);
-    const int q = sample_pos[s];
+    const int trow = sample_row[s];                                       // neighbour-table row of the sample
+    const int q = owned_pos ? owned_pos[trow] : trow + q_begin;           // its id in the point array the table refers to
     int* dst = table + row * pitch;
-    for (int j = threadIdx.x; j <= n; j += 256) dst[j] = j == 0 ? q : nbr_pos[(int64_t)q * nbr_pitch + (j - 1)];
+    for (int j = threadIdx.x; j <= n; j += 256) dst[j] = j == 0 ? q : nbr_pos[(int64_t)trow * nbr_pitch + (j - 1)];
     if (threadIdx.x == 0) { cnt[row] = n + 1; row_query[row] = q; }
 }
 
@@ -482,7 +486,6 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
 
 // fit from the device-resident neighbour table left by the sweep
 int pct_launch_fit_table(pct_ctx* ctx) {
-    const int64_t n = ctx->n;
     const int64_t nq = ctx->q_end - ctx->q_begin;
     PCT_TRY(pct_reserve(ctx, &ctx->coefs, (size_t)nq * 6 * sizeof(float)));
     PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)nq * sizeof(float)));
@@ -495,7 +498,9 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     a.table = (const int*)ctx->nbr_pos.p;
     a.cnt = ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr;
     a.row_query = nullptr;
-    a.rows = n;
+    a.row_query32 = sorted ? (const int*)ctx->owned_pos.p : nullptr;    // table row -> sorted position of its query
+    a.row_offset = sorted ? 0 : ctx->q_begin;                           // exhaustive sweep: row = public index - q_begin
+    a.rows = nq;
     a.k = ctx->k;
     a.pitch = ctx->nbr_pitch;
     a.out_by_row = 0;
@@ -542,10 +547,11 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
     return PCT_OK;
 }
 
-int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samples, int n_lo, int n_hi, int* d_table,
+int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_row, int64_t n_samples, int n_lo, int n_hi, int* d_table,
                            int pitch, int* d_cnt, int64_t* d_row_query) {
     const int64_t rows = n_samples * (n_hi - n_lo + 1);
-    hipLaunchKernelGGL(k_prefix_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_sample_pos, n_samples, n_lo, n_hi,
+    hipLaunchKernelGGL(k_prefix_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_sample_row,
+                       ctx->knn_sorted_space ? (const int*)ctx->owned_pos.p : nullptr, (int)ctx->q_begin, n_samples, n_lo, n_hi,
                        (const int*)ctx->nbr_pos.p, ctx->nbr_pitch, d_table, pitch, d_cnt, d_row_query);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;

@@ -2,10 +2,10 @@
 // stands where the reference builds scipy's cKDTree, pointCloudToolbox.py:74).
 //
 //   pack      xyz (n,3) f32 -> float4 {x,y,z,index}; finite check; bbox partials
-//   hist      cell id per point + per-cell counts (integer atomics)
+//   hist      cell id per point + per-cell counts of owned / other points (integer atomics)
 //   occupancy mean points-per-cell as seen by a point (drives the cell size)
 //   scan      exclusive scan of the counts -> cell starts, ordered occupied list
-//   scatter   counting sort of the float4 records into cell order
+//   scatter   counting sort of the float4 records into cell order, owned points first in each cell
 //
 // All kernels are HBM/L2 streaming passes over 16 B records with 64-wide waves.
 #include "pct_internal.h"
@@ -98,9 +98,15 @@ __device__ __forceinline__ int cell_coord(double x, double o, double inv, int n)
     return min(max(c, 0), n - 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4, int64_t n, pct_grid g,
+// Cell id per point and per-cell populations.  Points this handle owns (public
+// index in [q_begin, q_end), the multi-GPU shard) and the others are counted
+// separately: inside a cell the owned points are stored first, so that work
+// items and neighbour-table rows exist for owned queries only.  The value an
+// integer atomic returns is the point's arrival rank in its class -- the
+// scatter then needs no second atomic pass.
+__global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4, int64_t n, pct_grid g, int q_begin, int q_end,
                                                  int* __restrict__ cell_of, int* __restrict__ rank_of,
-                                                 int* __restrict__ cell_cnt) {
+                                                 int* __restrict__ cell_own, int* __restrict__ cell_oth) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pts4[i];
@@ -109,123 +115,144 @@ __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4
     int cz = cell_coord((double)p.z, g.oz, g.inv_cell, g.nz);
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_of[i] = c;
-    rank_of[i] = atomicAdd(&cell_cnt[c], 1);      // arrival rank inside the cell: the scatter needs no second atomic
+    if (i >= q_begin && i < q_end)
+        rank_of[i] = atomicAdd(&cell_own[c], 1);
+    else
+        rank_of[i] = atomicAdd(&cell_oth[c], 1) | (int)0x80000000;
 }
 
-// ---- dual exclusive scan: counts -> starts, ceil(count/items_q) -> work-item rank ------
+// ---- triple exclusive scan over the cells ---------------------------------
+//   x: all points      -> cell_start   (position of the cell in the sorted cloud)
+//   y: work items      -> item rank    (ceil(owned / items_q) per cell)
+//   z: owned points    -> own_start    (first neighbour-table row of the cell)
 constexpr int kScanItems = 8;                    // per thread
 constexpr int kScanTile = kBlock * kScanItems;   // 2048 cells per block
 
-__device__ __forceinline__ int2 block_reduce2(int2 v, int2* sh) {
-    for (int o = 32; o > 0; o >>= 1) {
-        v.x += __shfl_xor(v.x, o);
-        v.y += __shfl_xor(v.y, o);
-    }
-    int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) sh[w] = v;
-    __syncthreads();
-    int2 t = make_int2(0, 0);
-    for (int i = 0; i < kBlock / 64; ++i) { t.x += sh[i].x; t.y += sh[i].y; }
-    __syncthreads();
-    return t;
+__device__ __forceinline__ int4 add3(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, 0); }
+
+__device__ __forceinline__ int4 cell_counts(const int* __restrict__ own, const int* __restrict__ oth, int64_t c, int64_t ncell, int items_q) {
+    if (c >= ncell) return make_int4(0, 0, 0, 0);
+    const int o = own[c];
+    const int t = o + (oth ? oth[c] : 0);
+    return make_int4(t, (o + items_q - 1) / items_q, o, 0);
 }
 
-// first scan pass; also accumulates sum_c count_c^2 (= sum over points of the population of their own cell),
-// the statistic the cell-size loop steers on
-__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ cnt, int64_t ncell, int items_q, int2* __restrict__ tmp,
-                                                      unsigned long long* __restrict__ sumsq) {
-    __shared__ int2 sh[kBlock / 64];
+// first pass: per-tile sums; also accumulates sum_c count_c^2 (= sum over points of the population of
+// their own cell), the statistic the cell-size loop steers on
+__global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ own, const int* __restrict__ oth, int64_t ncell, int items_q,
+                                                      int4* __restrict__ tmp, unsigned long long* __restrict__ sumsq) {
+    __shared__ int4 sh[kBlock / 64];
     unsigned long long sq = 0;
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    int2 v = make_int2(0, 0);
+    int4 v = make_int4(0, 0, 0, 0);
     for (int j = 0; j < kScanItems; ++j) {
-        int64_t c = base + j;
-        int x = c < ncell ? cnt[c] : 0;
-        v.x += x;
-        v.y += (x + items_q - 1) / items_q;
-        sq += (unsigned long long)x * (unsigned)x;
+        const int4 x = cell_counts(own, oth, base + j, ncell, items_q);
+        v = add3(v, x);
+        sq += (unsigned long long)x.x * (unsigned)x.x;
     }
-    int2 t = block_reduce2(v, sh);
-    if (threadIdx.x == 0) tmp[blockIdx.x] = t;
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-    if ((threadIdx.x & 63) == 0 && sq) atomicAdd(sumsq, sq);
+    for (int o = 32; o > 0; o >>= 1) {
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o);
+        sq += __shfl_xor(sq, o);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        sh[threadIdx.x >> 6] = v;
+        if (sq) atomicAdd(sumsq, sq);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int4 t = make_int4(0, 0, 0, 0);
+        for (int i = 0; i < kBlock / 64; ++i) t = add3(t, sh[i]);
+        tmp[blockIdx.x] = t;
+    }
 }
 
 // single block: exclusive scan of the per-tile sums; totals to tmp[nblk]
-__global__ __launch_bounds__(1024) void k_scan_tiles(int2* __restrict__ tmp, int nblk) {
-    __shared__ int2 sh[1024];
-    __shared__ int2 carry;
-    if (threadIdx.x == 0) carry = make_int2(0, 0);
+__global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int nblk) {
+    __shared__ int4 sh[1024];
+    __shared__ int4 carry;
+    if (threadIdx.x == 0) carry = make_int4(0, 0, 0, 0);
     __syncthreads();
     for (int base = 0; base < nblk; base += 1024) {
         int i = base + threadIdx.x;
-        int2 v = i < nblk ? tmp[i] : make_int2(0, 0);
+        int4 v = i < nblk ? tmp[i] : make_int4(0, 0, 0, 0);
         sh[threadIdx.x] = v;
         __syncthreads();
         for (int o = 1; o < 1024; o <<= 1) {
-            int2 a = make_int2(0, 0);
+            int4 a = make_int4(0, 0, 0, 0);
             if ((int)threadIdx.x >= o) a = sh[threadIdx.x - o];
             __syncthreads();
-            sh[threadIdx.x].x += a.x;
-            sh[threadIdx.x].y += a.y;
+            sh[threadIdx.x] = add3(sh[threadIdx.x], a);
             __syncthreads();
         }
-        int2 incl = sh[threadIdx.x];
-        int2 c = carry;
-        if (i < nblk) tmp[i] = make_int2(c.x + incl.x - v.x, c.y + incl.y - v.y);
+        int4 incl = sh[threadIdx.x];
+        int4 c = carry;
+        if (i < nblk) tmp[i] = make_int4(c.x + incl.x - v.x, c.y + incl.y - v.y, c.z + incl.z - v.z, 0);
         __syncthreads();
-        if (threadIdx.x == 1023) carry = make_int2(c.x + incl.x, c.y + incl.y);
+        if (threadIdx.x == 1023) carry = add3(c, incl);
         __syncthreads();
     }
     if (threadIdx.x == 0) tmp[nblk] = carry;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scan_apply(int* __restrict__ cnt, int64_t ncell, int items_q,
-                                                       const int2* __restrict__ tmp, int2* __restrict__ items) {
-    __shared__ int2 sh[kBlock];
+__global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ own, const int* __restrict__ oth, int64_t ncell, int items_q,
+                                                       const int4* __restrict__ tmp, int* __restrict__ cell_start,
+                                                       int* __restrict__ own_start, int2* __restrict__ items) {
+    __shared__ int4 sh[kBlock];
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
-    int x[kScanItems];
-    int2 v = make_int2(0, 0);
+    int4 x[kScanItems];
+    int4 v = make_int4(0, 0, 0, 0);
     for (int j = 0; j < kScanItems; ++j) {
-        int64_t c = base + j;
-        x[j] = c < ncell ? cnt[c] : 0;
-        v.x += x[j];
-        v.y += (x[j] + items_q - 1) / items_q;
+        x[j] = cell_counts(own, oth, base + j, ncell, items_q);
+        v = add3(v, x[j]);
     }
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = 1; o < kBlock; o <<= 1) {
-        int2 a = make_int2(0, 0);
+        int4 a = make_int4(0, 0, 0, 0);
         if ((int)threadIdx.x >= o) a = sh[threadIdx.x - o];
         __syncthreads();
-        sh[threadIdx.x].x += a.x;
-        sh[threadIdx.x].y += a.y;
+        sh[threadIdx.x] = add3(sh[threadIdx.x], a);
         __syncthreads();
     }
-    int2 off = tmp[blockIdx.x];
+    const int4 off = tmp[blockIdx.x];
     int s = off.x + sh[threadIdx.x].x - v.x;
     int r = off.y + sh[threadIdx.x].y - v.y;
+    int w = off.z + sh[threadIdx.x].z - v.z;
     for (int j = 0; j < kScanItems; ++j) {
         int64_t c = base + j;
         if (c < ncell) {
-            cnt[c] = s;
-            for (int ch = 0; ch * items_q < x[j]; ++ch) items[r++] = make_int2((int)c, ch);
-            s += x[j];
+            cell_start[c] = s;
+            own_start[c] = w;
+            for (int ch = 0; ch < x[j].y; ++ch) items[r++] = make_int2((int)c, ch);
+            s += x[j].x;
+            w += x[j].z;
         }
     }
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) cnt[ncell] = s;  // == n
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { cell_start[ncell] = s; own_start[ncell] = w; }
 }
 
+// counting-sort scatter, owned points first inside every cell; also records for every public index its
+// neighbour-table row (-1 if not owned) and for every row its sorted position
 __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ pts4, const int* __restrict__ cell_of,
-                                                    const int* __restrict__ cell_start, const int* __restrict__ rank_of,
-                                                    int64_t n, float4* __restrict__ sorted4, int* __restrict__ pos_of,
+                                                    const int* __restrict__ cell_start, const int* __restrict__ cell_own,
+                                                    const int* __restrict__ own_start, const int* __restrict__ rank_of,
+                                                    int64_t n, float4* __restrict__ sorted4, int* __restrict__ row_of,
+                                                    int* __restrict__ owned_pos,
                                                     const double4* __restrict__ pts4d, double4* __restrict__ sorted4d) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
-    int c = cell_of[i];
-    int pos = cell_start[c] + rank_of[i];
+    const int c = cell_of[i];
+    const int r = rank_of[i];
+    int pos, row = -1;
+    if (r >= 0) {
+        pos = cell_start[c] + r;
+        row = own_start[c] + r;
+        owned_pos[row] = pos;
+    } else {
+        pos = cell_start[c] + cell_own[c] + (r & 0x7fffffff);
+    }
     sorted4[pos] = pts4[i];
-    pos_of[i] = pos;
+    row_of[i] = row;
     if (pts4d) sorted4d[pos] = pts4d[i];
 }
 
@@ -309,6 +336,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
 
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
+    const bool sharded = ctx->q_begin > 0 || ctx->q_end < n;             // some points are candidates only
     const int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
     ctx->items_q = items_q;
     int nblk = 0;
@@ -323,17 +351,21 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
             a *= cbrt((double)g.ncell / (double)cell_cap) * 1.01;
             set_dims(&g, bbox, a);
         }
-        PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
-        PCT_HIP(ctx, hipMemsetAsync(ctx->cell_cnt.p, 0, (size_t)(g.ncell + 1) * sizeof(int), ctx->stream));
+        PCT_TRY(pct_reserve(ctx, &ctx->cell_own, (size_t)g.ncell * sizeof(int)));
+        PCT_HIP(ctx, hipMemsetAsync(ctx->cell_own.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
+        if (sharded) {
+            PCT_TRY(pct_reserve(ctx, &ctx->cell_oth, (size_t)g.ncell * sizeof(int)));
+            PCT_HIP(ctx, hipMemsetAsync(ctx->cell_oth.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
+        }
         PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 16, ctx->stream));
         hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, n, g, (int*)ctx->cell_of.p, (int*)ctx->cell_fill.p,
-                           (int*)ctx->cell_cnt.p);
+                           (const float4*)ctx->pts4.p, n, g, (int)ctx->q_begin, (int)ctx->q_end, (int*)ctx->cell_of.p,
+                           (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
-        PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int2)));
+        PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4)));
         hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                           (const int*)ctx->cell_cnt.p, g.ncell, items_q, (int2*)ctx->scan_tmp.p,
-                           (unsigned long long*)ctx->red.p);
+                           (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
+                           (int4*)ctx->scan_tmp.p, (unsigned long long*)ctx->red.p);
         PCT_HIP(ctx, hipGetLastError());
         unsigned long long s2 = 0;
         PCT_HIP(ctx, hipMemcpyAsync(&s2, ctx->red.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -363,26 +395,33 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->tm.cell_size = g.cell;
 
     // rest of the exclusive scan + ordered work-item list
-    PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n < g.ncell ? n : g.ncell) + (size_t)n / items_q + 16) * sizeof(int2)));
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int2*)ctx->scan_tmp.p, nblk);
+    const int64_t n_owned = ctx->q_end - ctx->q_begin;
+    PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->own_start, (size_t)(g.ncell + 1) * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n_owned < g.ncell ? n_owned : g.ncell) + (size_t)n_owned / items_q + 16) * sizeof(int2)));
+    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk);
     hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                       (int*)ctx->cell_cnt.p, g.ncell, items_q, (const int2*)ctx->scan_tmp.p, (int2*)ctx->occ.p);
+                       (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
+                       (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
     PCT_HIP(ctx, hipGetLastError());
-    int2 tot;
-    PCT_HIP(ctx, hipMemcpyAsync(&tot, (int2*)ctx->scan_tmp.p + nblk, sizeof(int2), hipMemcpyDeviceToHost, ctx->stream));
+    int4 tot;
+    PCT_HIP(ctx, hipMemcpyAsync(&tot, (int4*)ctx->scan_tmp.p + nblk, sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
 
     // counting-sort scatter
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
-    PCT_TRY(pct_reserve(ctx, &ctx->pos_of, (size_t)n * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)n * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, (size_t)n_owned * sizeof(int)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
     hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                        (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
-                       (const int*)ctx->cell_fill.p, n, (float4*)ctx->sorted4.p, (int*)ctx->pos_of.p,
+                       (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
+                       (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
                        ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
                        ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (tot.x != n) return pct_fail(ctx, PCT_ERR_INVALID, "cell scan total %d != n %lld", tot.x, (long long)n);
+    if (tot.x != n || tot.z != n_owned)
+        return pct_fail(ctx, PCT_ERR_INVALID, "cell scan totals %d/%d != %lld/%lld", tot.x, tot.z, (long long)n, (long long)n_owned);
     ctx->n_items = tot.y;
     ctx->n_occ = tot.y;
     ctx->tm.occupied_cells = tot.y;

@@ -47,8 +47,11 @@ struct pct_ctx {
     // grid
     pct_grid grid = {};
     pct_buf cell_of;    // int32 (n) cell id per public point
-    pct_buf cell_cnt;   // int32 (ncell+1) counts -> exclusive starts
-    pct_buf cell_fill;  // int32 (ncell) scatter cursors
+    pct_buf cell_cnt;   // int32 (ncell+1) exclusive cell starts in the sorted cloud
+    pct_buf cell_own;   // int32 (ncell) owned points per cell (stored first inside the cell)
+    pct_buf cell_oth;   // int32 (ncell) other points per cell (sharded handles only)
+    pct_buf own_start;  // int32 (ncell+1) first neighbour-table row of every cell
+    pct_buf cell_fill;  // int32 (n) arrival rank of every point in its cell and class
     pct_buf scan_tmp;   // block sums
     pct_buf occ;        // int2 (n_items) work items {cell id, chunk of items_q queries}
     pct_buf redo;       // int32 (n) queries the fast sweep handed to the exact sweep
@@ -56,13 +59,14 @@ struct pct_ctx {
     int32_t items_q = 12;
     pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
     pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
-    pct_buf pos_of;     // int32 (n) sorted position of every public index
+    pct_buf row_of;     // int32 (n) neighbour-table row of every public index (-1 = not owned)
+    pct_buf owned_pos;  // int32 (owned) sorted position of every table row
     pct_buf red;        // small reduction scratch
     int64_t n_occ = 0;
     bool grid_valid = false;
     bool pts4_valid = false;
 
-    // neighbour table in sorted space: row = sorted position of the query
+    // neighbour table: one row per OWNED query (cell order, see own_start); entries are sorted positions
     pct_buf nbr_pos;    // int32 (n,k) sorted positions of the neighbours
     pct_buf nbr_dist;   // float (n,k)
     pct_buf nbr_cnt;    // int32 (n)

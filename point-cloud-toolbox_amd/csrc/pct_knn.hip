@@ -35,6 +35,10 @@ struct KnnArgs {
     const float4* pts;        // candidate records {x,y,z,public index}; cell-sorted (grid) or public order (brute)
     const double4* ptsd;      // native fp64 query coordinates in the same order (nullable)
     const int* cell_start;    // grid only
+    const int* cell_own;      // grid only: owned points per cell (they come first inside the cell)
+    const int* own_start;     // grid only: first table row of every cell
+    const int* owned_pos;     // grid only: sorted position of every table row
+    int64_t n_owned;          // rows of the neighbour table
     const int* occ;           // grid only
     int64_t n_occ;
     int64_t n;
@@ -356,7 +360,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
     const int lane = lane_id();
     const pct_grid g = a.g;
     const int* __restrict__ cs = a.cell_start;
-    const int64_t total = list ? (int64_t)*list_count : a.n;
+    const int64_t total = list ? (int64_t)*list_count : a.n_owned;
     const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
 
     Sweep<R> sw;
@@ -367,10 +371,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
     sw.pend_p = s_pend_p[w];
 
     for (int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w; item < total; item += nwaves) {
-        const int q = list ? list[item] : (int)item;
+        const int row = list ? list[item] : (int)item;          // neighbour-table row (owned queries only)
+        const int q = a.owned_pos[row];
         const float4 qp = a.pts[q];
-        const int pub = __builtin_amdgcn_readfirstlane(__float_as_int(qp.w));
-        if (pub < a.q_begin || pub >= a.q_end) continue;
         // the query's cell comes from its float32 (tree) coordinates, as in the build
         const int cx = __builtin_amdgcn_readfirstlane(cell_coord_d((double)qp.x, g.ox, g.inv_cell, g.nx));
         const int cy = __builtin_amdgcn_readfirstlane(cell_coord_d((double)qp.y, g.oy, g.inv_cell, g.ny));
@@ -404,7 +407,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             it.start(it.ring + 1, false);
         }
         if (a.stats && lane == 0 && it.ring > 1) atomicAdd(&a.counters[0], 1ull);
-        sw.store(q, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+        sw.store(row, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
     }
 }
 
@@ -500,9 +503,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     const int cx = cell % g.nx;
     const int cy = (cell / g.nx) % g.ny;
     const int cz = cell / (g.nx * g.ny);
-    const int qs = cs[cell] + chunk * items_q;
-    const int qe = min(cs[cell + 1], qs + items_q);
+    const int qs = cs[cell] + chunk * items_q;                       // owned points sit first in the cell
+    const int qe = min(cs[cell] + a.cell_own[cell], qs + items_q);
     const int nq = qe - qs;
+    const int row0 = a.own_start[cell] + chunk * items_q;            // neighbour-table row of query qs
 
     // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
     float* cand_x = s_cx[w];
@@ -537,18 +541,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
 
     if (m > CAP) {
         // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
-        const int pub = __float_as_int(my_q.w);
-        const bool mine = lane < nq && pub >= a.q_begin && pub < a.q_end;
-        const unsigned long long mk = __ballot(mine);
-        if (mk) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(redo_count, (int)__popcll(mk));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (mine) redo[base + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0))] = qs + lane;
-        }
+        int base = 0;
+        if (lane == 0) base = atomicAdd(redo_count, nq);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < nq) redo[base + lane] = row0 + lane;
         if (a.stats && lane == 0) {
             atomicAdd(&a.counters[1], 1ull);
-            atomicAdd(&a.counters[4], (unsigned long long)__popcll(mk));
+            atomicAdd(&a.counters[4], (unsigned long long)nq);
         }
         return;
     }
@@ -578,9 +577,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     const unsigned key_max = (1u << KEY_BITS) - 1u;
 
     for (int qi = 0; qi < nq; ++qi) {
-        const int q = qs + qi;
-        const int pub = __builtin_amdgcn_readlane(__float_as_int(my_q.w), qi);
-        if (pub < a.q_begin || pub >= a.q_end) continue;
+        const int row = row0 + qi;
         double qx, qy, qz;
         if (a.ptsd) {
             qx = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.x), qi), __builtin_amdgcn_readlane(__double2loint(my_qd.x), qi));
@@ -685,7 +682,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             }
         }
         if (__ballot(amb) != 0ull) {
-            if (lane == 0) redo[atomicAdd(redo_count, 1)] = q;
+            if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
             ++n_redo;
             continue;
         }
@@ -709,14 +706,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
                     pos = j + o;                                      // sorted position of staged slot j
                     dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
                 }
-                a.nbr_pos[(int64_t)q * a.pitch + (i - 1)] = pos;
-                a.nbr_dist[(int64_t)q * a.pitch + (i - 1)] = dist;
+                a.nbr_pos[(int64_t)row * a.pitch + (i - 1)] = pos;
+                a.nbr_dist[(int64_t)row * a.pitch + (i - 1)] = dist;
                 found += real;
             }
         }
         if (a.nbr_cnt) {
             for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
-            if (lane == 0) a.nbr_cnt[q] = found;
+            if (lane == 0) a.nbr_cnt[row] = found;
         }
     }
     // statistics are opt-in: ~10^5 waves adding to the same words serialise at the memory side
@@ -769,20 +766,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_brute(KnnArgs a) {
         if (sw.npend > 0 || sw.empty) sw.flush();
         if (!have) break;
     }
-    sw.store(q, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+    sw.store(q - a.q_begin, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
 }
 
-// sorted-space table -> public (rows,k) arrays for public rows [begin,end)
-__global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ nbr_pos,
-                                                const float* __restrict__ nbr_dist, const int* __restrict__ nbr_cnt,
-                                                int64_t n, int k, int pitch, int64_t begin, int64_t end,
-                                                int* __restrict__ idx_out, float* __restrict__ dist_out,
-                                                int* __restrict__ cnt_out) {
+// neighbour table -> public (rows,k) arrays for public rows [begin,end).  owned_pos == nullptr: the table came
+// from the exhaustive sweep (row = public index - q_begin, entries = public indices).
+__global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ owned_pos, int q_begin,
+                                                const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
+                                                const int* __restrict__ nbr_cnt, int64_t n, int64_t n_rows, int k, int pitch,
+                                                int64_t begin, int64_t end, int* __restrict__ idx_out,
+                                                float* __restrict__ dist_out, int* __restrict__ cnt_out) {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t row = t / k;
     const int j = (int)(t - row * k);
-    if (row >= n) return;
-    const int pub = __float_as_int(pts[row].w);
+    if (row >= n_rows) return;
+    const int pub = owned_pos ? __float_as_int(pts[owned_pos[row]].w) : (int)row + q_begin;
     if (pub < begin || pub >= end) return;
     const int64_t o = (int64_t)(pub - begin) * k + j;
     const int pos = nbr_pos[row * pitch + j];
@@ -792,14 +790,14 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
 }
 
 // the same for an explicit list of public rows (one block per listed row)
-__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ pos_of,
+__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ row_of, int q_begin,
                                                      const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
                                                      const int* __restrict__ nbr_cnt, int64_t n, int k, int pitch,
                                                      const int64_t* __restrict__ rows, int* __restrict__ idx_out,
                                                      float* __restrict__ dist_out, int* __restrict__ cnt_out) {
     const int64_t r = blockIdx.x;
     const int64_t pub = rows[r];
-    const int64_t row = pos_of ? pos_of[pub] : pub;
+    const int64_t row = row_of ? row_of[pub] : pub - q_begin;
     for (int j = threadIdx.x; j < k; j += 128) {
         const int pos = nbr_pos[row * pitch + j];
         if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
@@ -827,6 +825,10 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     a.pts = (const float4*)(grid ? ctx->sorted4.p : ctx->pts4.p);
     a.ptsd = ctx->has_f64 ? (const double4*)(grid ? ctx->sorted4d.p : ctx->pts4d.p) : nullptr;
     a.cell_start = (const int*)ctx->cell_cnt.p;
+    a.cell_own = (const int*)ctx->cell_own.p;
+    a.own_start = (const int*)ctx->own_start.p;
+    a.owned_pos = (const int*)ctx->owned_pos.p;
+    a.n_owned = ctx->q_end - ctx->q_begin;
     a.occ = (const int*)ctx->occ.p;
     a.n_occ = ctx->n_occ;
     a.n = ctx->n;
@@ -846,9 +848,10 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
 
 int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
     ctx->nbr_pitch = (k + 3) & ~3;                        // 16-byte aligned rows (the fit kernel reads int4)
-    PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, (size_t)ctx->n * ctx->nbr_pitch * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, (size_t)ctx->n * ctx->nbr_pitch * sizeof(float)));
-    if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, (size_t)ctx->n * sizeof(int)));
+    const size_t rows = (size_t)(ctx->q_end - ctx->q_begin);     // one row per owned query
+    PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, rows * ctx->nbr_pitch * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, rows * ctx->nbr_pitch * sizeof(float)));
+    if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, rows * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
     PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
     return PCT_OK;
@@ -858,7 +861,7 @@ int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
 
 int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     PCT_TRY(reserve_table(ctx, k, eps));
-    PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)ctx->n + 16) * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)(ctx->q_end - ctx->q_begin) + 16) * sizeof(int)));
     KnnArgs a = make_args(ctx, k, eps, true);
     int* redo_count = (int*)ctx->counters.p + 14;            // counters buffer: 8 x u64, last int pair reserved
     int* redo = (int*)ctx->redo.p;
@@ -877,7 +880,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     }
     // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
     {
-        const int64_t waves = exact_only ? ctx->n : 8192;
+        const int64_t waves = exact_only ? (ctx->q_end - ctx->q_begin) : 8192;
         const int blocks = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
         const int* list = exact_only ? nullptr : redo;
         if (k + 1 <= 64)
@@ -908,12 +911,15 @@ int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps) {
 
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_t* d_idx, float* d_dist,
                                 int32_t* d_cnt) {
-    const float4* pts = (const float4*)(ctx->knn_sorted_space ? ctx->sorted4.p : ctx->pts4.p);
-    const int64_t total = ctx->n * ctx->k;
+    const bool sorted = ctx->knn_sorted_space;
+    const int64_t n_rows = ctx->q_end - ctx->q_begin;
+    const int64_t total = n_rows * ctx->k;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream, pts, (const int*)ctx->nbr_pos.p,
-                       (const float*)ctx->nbr_dist.p, ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n,
-                       ctx->k, ctx->nbr_pitch, begin, end, d_idx, d_dist, d_cnt);
+    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream,
+                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->owned_pos.p : nullptr,
+                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
+                       ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, n_rows, ctx->k, ctx->nbr_pitch, begin, end,
+                       d_idx, d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -921,8 +927,8 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt) {
     const bool sorted = ctx->knn_sorted_space;
     hipLaunchKernelGGL(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
-                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->pos_of.p : nullptr,
-                       (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
+                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->row_of.p : nullptr,
+                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, ctx->k, ctx->nbr_pitch, d_rows, d_idx,
                        d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());
