@@ -83,6 +83,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
 
+    force_dist = os.environ.get("PCT_FORCE_DIST") == "1"       # rehearse the multi-GPU code path with one rank
+    dist = torch = None
+    if world > 1 or force_dist:
+        # torch ships its own libamdhip64.so.7: it must be loaded BEFORE libpct_hip.so so that the process has one
+        # HIP runtime (the loader then binds our library to the copy that is already there)
+        import torch
+        import torch.distributed as dist
+
     import __graft_entry__ as ge
     ge.build()
     from point_cloud_toolbox_amd import _capi, shapes
@@ -93,21 +101,23 @@ def main():
     lo, hi = shard_range(n_total, rank, world)
     local = shapes.torus_random(n_total, seed=1234, lo=lo, hi=hi)
 
-    dist = torch = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
+    if dist is not None:
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if force_dist and "RANK" not in os.environ:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     handle = _capi.Handle(local_rank)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
         handle.synchronize()
 
-    if world == 1:
+    if dist is None:
         handle.set_points(local)                              # resident before the timed region
 
         def step():
@@ -136,7 +146,7 @@ def main():
         knn_ms += tm["knn_ms"]; fit_ms += tm["fit_ms"]; grid_ms += tm["grid_ms"]
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=torch.device("cuda", local_rank))
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -170,7 +180,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(local, k)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
         print(json.dumps(out))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     handle.close()

@@ -10,6 +10,11 @@ global, and results are independent of G.
 
 ``torch.distributed`` is plumbing here (process group, RCCL all-gather when the
 backend is "nccl", gloo on CPU); the compute goes through the C ABI.
+
+Load order: PyTorch-ROCm bundles its own ``libamdhip64.so.7``.  A process that
+uses both must ``import torch`` BEFORE the first ``_capi.load()`` so that the
+dynamic loader binds ``libpct_hip.so`` to the HIP runtime that is already
+loaded; two HIP runtimes in one process cannot both open the device.
 """
 from __future__ import annotations
 

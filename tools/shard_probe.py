@@ -1,0 +1,25 @@
+"""Per-rank cost of a G-way sharded step, measured on one GPU (developer tool): rank 0's share of a G x 1M cloud."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge
+ge.build()
+from point_cloud_toolbox_amd import _capi, shapes
+from point_cloud_toolbox_amd.dist import shard_range
+per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+for G in (1, 2, 4, 8):
+    n = per * G
+    pts = shapes.torus_random(n, seed=1234)
+    h = _capi.Handle(0)
+    h.set_points(pts)
+    lo, hi = shard_range(n, G - 1, G)
+    h.set_query_range(lo, hi)
+    best = None
+    for _ in range(4):
+        h.curvature(50, 0.0, _capi.KNN_GRID)
+        t = h.timings()
+        if best is None or t["total_ms"] < best["total_ms"]:
+            best = t
+    print(f"G={G} N={n}: grid {best['grid_ms']:.3f} knn {best['knn_ms']:.3f} fit {best['fit_ms']:.3f} total {best['total_ms']:.3f} ms "
+          f"-> {G * per / best['total_ms'] / 1e3:.1f} Mpts/s aggregate if all ranks alike (no all-gather)", flush=True)
+    h.close()
