@@ -575,6 +575,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     const double eps2 = a.eps2;
     const double scale = (double)(1u << KEY_BITS) / (12.1 * g.cell * g.cell);
     const unsigned key_max = (1u << KEY_BITS) - 1u;
+    // Per query, the largest key the stencil can vouch for: lane l evaluates query l once per item (the radius
+    // guaranteed by the 27-cell cube depends on where the query sits inside its cell).  floor() keeps it conservative.
+    unsigned my_gkey;
+    {
+        const double lqx = a.ptsd ? my_qd.x : (double)my_q.x, lqy = a.ptsd ? my_qd.y : (double)my_q.y,
+                     lqz = a.ptsd ? my_qd.z : (double)my_q.z;
+        const double gx = (lqx - g.ox) * g.inv_cell - cx;
+        const double gy = (lqy - g.oy) * g.inv_cell - cy;
+        const double gz = (lqz - g.oz) * g.inv_cell - cz;
+        my_gkey = (unsigned)(guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1) * scale);     // saturates: +inf -> 0xFFFFFFFF
+    }
+    // ceil(eps^2 * scale): the whole eps ball must be inside the guaranteed radius too
+    const unsigned eps_key = eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
 
     for (int qi = 0; qi < nq; ++qi) {
         const int row = row0 + qi;
@@ -594,6 +607,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         for (int r = 0; r < R; ++r) best.e[r] = kPadElem;
         unsigned tau = kPadElem;         // element k of best (wave-uniform)
         int npend = 0;
+        bool empty = true;               // best holds no element yet
         bool amb = false;                // per-lane: a key collision that could matter was seen
 
         float cnx = 0.f, cny = 0.f, cnz = 0.f;                  // LDS reads of the next step, issued one step ahead
@@ -638,10 +652,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
                 wave_lds_sync();
                 npend = rest;
                 fast_sort_from<R, 2, true>(b);                 // descending
-                // (a first batch meets an all-padding list: the same merge then simply reverses it)
+                if (empty) {
+                    // first batch: the running list is this batch in ascending order = lanes (and slots) reversed
 #pragma unroll
-                for (int r = 0; r < R; ++r) best.e[r] = min(b.e[r], best.e[r]);
-                fast_strides<R, 64 * R, 32 * R, false>(best);
+                    for (int r = 0; r < R; ++r) {
+                        int v = __builtin_amdgcn_mov_dpp((int)b.e[R - 1 - r], 0x140, 0xF, 0xF, true);   // row_mirror
+                        v = lane_xor<16>(v);
+                        best.e[r] = (unsigned)lane_xor<32>(v);
+                    }
+                    empty = false;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) best.e[r] = min(b.e[r], best.e[r]);
+                    fast_strides<R, 64 * R, 32 * R, false>(best);
+                }
                 // threshold = element k; the tail beyond it must not share its key
                 {
                     const int sl = k >> 6, src = k & 63;
@@ -658,13 +682,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             if (!have) break;
         }
 
-        // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up)
+        // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up; all in key units)
         {
-            const double gx = (qx - g.ox) * g.inv_cell - cx;
-            const double gy = (qy - g.oy) * g.inv_cell - cy;
-            const double gz = (qz - g.oz) * g.inv_cell - cz;
-            const double tau_ub = tau == kPadElem ? (double)INFINITY : (double)((tau >> SLOT_BITS) + 1u) / scale;
-            amb |= !(fmin(tau_ub, eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1));
+            const unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
+            const unsigned need = min((tau >> SLOT_BITS) + 1u, eps_key);     // padding: 2^KEY_BITS, never vouched for
+            amb |= need > gkey;
         }
         // ---- neighbours with equal keys inside the first k+2 entries: order not proven
         {
