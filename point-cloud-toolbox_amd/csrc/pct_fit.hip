@@ -168,11 +168,26 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     const int64_t row0 = (int64_t)blockIdx.x * kFitBlock;
     const int k = a.k, kp = a.kp;
 
-    // ---- stage 64 index rows, coalesced ---------------------------------
+    // ---- stage 64 index rows: 16 lanes x int4 per row, 4 rows per load instruction, all loads independent
+    // (rows are 16-byte aligned: pitch is a multiple of 4) -------------------------------------------------
     const int nrow = (int)min((int64_t)kFitBlock, a.rows - row0);
-    for (int r = 0; r < nrow; ++r) {
-        const int* src = a.table + (row0 + r) * a.pitch;
-        for (int j = lane; j < k; j += kFitBlock) s_idx[r * kp + j] = src[j];
+    {
+        const int sub = lane >> 4, c4 = (lane & 15) << 2;
+        for (int cb = 0; cb < k; cb += 64) {
+            const int c = cb + c4;
+#pragma unroll 4
+            for (int r0 = 0; r0 < kFitBlock; r0 += 4) {
+                const int r = r0 + sub;
+                if (r < nrow && c < a.pitch) {
+                    const int4 v = *(const int4*)(a.table + (row0 + r) * a.pitch + c);
+                    int* dst = s_idx + r * kp + c;
+                    if (c + 0 < k) dst[0] = v.x;
+                    if (c + 1 < k) dst[1] = v.y;
+                    if (c + 2 < k) dst[2] = v.z;
+                    if (c + 3 < k) dst[3] = v.w;
+                }
+            }
+        }
     }
     __syncthreads();
 

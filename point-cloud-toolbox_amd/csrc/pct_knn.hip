@@ -626,7 +626,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
                 const bool in_eps = valid && d2 < eps2;
                 const bool pass = in_eps && e < tau;
                 amb |= in_eps && ((e ^ tau) >> SLOT_BITS) == 0u;
-                const unsigned long long mask = __ballot(pass);
+                const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
                 if (pass) {
                     const int at = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                     pend[at] = e;
