@@ -128,6 +128,14 @@ int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t r
 int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int64_t n_samples,
                                    int32_t n_lo, int32_t n_hi, float* K_out);
 
+/* load_mesh_compute_energies (utils.py:702-765), the consumer of K/H: bending energy sum(mean(H^2) * area),
+ * stretching energy sum(mean(K) * area) (both nansum) and total area over a triangle mesh.  vertices (V,3)
+ * float64, triangles (T,3) int32, curvature arrays (V) float32 (curvature_is_f64 == 0, what the path
+ * produces) or float64; face means are taken in that dtype as NumPy does.  out3 = {bending, stretching, area}. */
+int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, const int32_t* triangles,
+                      int64_t n_triangles, const void* gaussian, const void* mean, int32_t curvature_is_f64,
+                      double* out3);
+
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
 /* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */

@@ -347,3 +347,27 @@ def curvature_tolerance_ok(x, ref, floor, rtol=1e-5):
     x = np.asarray(x, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return np.abs(x - ref) <= rtol * np.maximum(np.abs(ref), floor)
+
+
+# --------------------------------------------------------------------------
+# N3  load_mesh_compute_energies  (/root/reference/utils.py:702-765)
+# utils.py cannot be imported here (needs open3d / pyvista), so this restatement is pinned by the closed-form
+# energies the reference itself quotes (main_shape_validation.py:33-45: sphere 4*pi / 4*pi) -- "parity unpinned"
+# by a reference run.
+# --------------------------------------------------------------------------
+def mesh_energies(vertices, triangles, gaussian_curvature, mean_curvature):
+    vertices = np.asarray(vertices)
+    triangles = np.asarray(triangles)
+    areas = np.zeros(len(triangles))
+    for i, tri in enumerate(triangles):                               # utils.py:723-728
+        v0, v1, v2 = vertices[tri[0]], vertices[tri[1]], vertices[tri[2]]
+        areas[i] = 0.5 * np.linalg.norm(np.cross(v1 - v0, v2 - v0))
+    g = np.asarray(gaussian_curvature)
+    m = np.asarray(mean_curvature)
+    m2 = m ** 2                                                       # utils.py:745
+    fk = np.zeros(len(triangles)); fm2 = np.zeros(len(triangles))
+    for i, tri in enumerate(triangles):                               # utils.py:753-758
+        verts = np.array(tri)
+        fk[i] = np.mean(g[verts])
+        fm2[i] = np.mean(m2[verts])
+    return np.nansum(fm2 * areas), np.nansum(fk * areas), np.sum(areas)

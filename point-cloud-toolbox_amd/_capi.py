@@ -69,6 +69,7 @@ SIGNATURES = {
     "pct_get_fit": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p, _f32p]),
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
+    "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
     "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
     "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
     "pct_device_free": (C.c_int, [_p, _p]),
@@ -245,6 +246,20 @@ class Handle:
         self._check(self._lib.pct_neighbor_study_curvatures(self._h, _ptr(rows, _i64p), len(rows), int(n_lo), int(n_hi),
                                                            _ptr(out, _f32p)))
         return out
+
+    def mesh_energies(self, vertices, triangles, gaussian, mean):
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        f64 = np.asarray(gaussian).dtype == np.float64 and np.asarray(mean).dtype == np.float64
+        dt = np.float64 if f64 else np.float32
+        g = np.ascontiguousarray(gaussian, dtype=dt)
+        m = np.ascontiguousarray(mean, dtype=dt)
+        if len(g) != len(v) or len(m) != len(v):
+            raise ValueError("one curvature value per vertex is required")
+        out = np.zeros(3, np.float64)
+        self._check(self._lib.pct_mesh_energies(self._h, _ptr(v, _f64p), len(v), _ptr(t, _i32p), len(t), g.ctypes.data_as(_p),
+                                               m.ctypes.data_as(_p), int(f64), _ptr(out, _f64p)))
+        return float(out[0]), float(out[1]), float(out[2])
 
     def timings(self):
         t = Timings()

@@ -430,6 +430,35 @@ int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int6
     return PCT_OK;
 }
 
+int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, const int32_t* triangles, int64_t n_triangles,
+                      const void* gaussian, const void* mean, int32_t curvature_is_f64, double* out3) {
+    PCT_TRY(begin_call(ctx));
+    if (!vertices || !triangles || !gaussian || !mean || !out3 || n_vertices <= 0 || n_triangles < 0)
+        return pct_fail(ctx, PCT_ERR_INVALID, "bad mesh arguments");
+    out3[0] = out3[1] = out3[2] = 0.0;
+    if (n_triangles == 0) return PCT_OK;                               // utils.py:719-721: zeros
+    for (int64_t i = 0; i < 3 * n_triangles; ++i)
+        if (triangles[i] < 0 || triangles[i] >= n_vertices)
+            return pct_fail(ctx, PCT_ERR_INVALID, "triangle %lld refers to vertex %d outside [0,%lld)", (long long)(i / 3), triangles[i], (long long)n_vertices);
+    const size_t esz = curvature_is_f64 ? sizeof(double) : sizeof(float);
+    const int nblk = (int)((n_triangles + 255) / 256 < 1024 ? (n_triangles + 255) / 256 : 1024);
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)n_vertices * 3 * sizeof(double)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)n_triangles * 3 * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)n_vertices * 2 * esz));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_d, ((size_t)nblk * 3 + 3) * sizeof(double)));
+    char* d_kh = (char*)ctx->stage_c.p;
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, vertices, (size_t)n_vertices * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_b.p, triangles, (size_t)n_triangles * 3 * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(d_kh, gaussian, (size_t)n_vertices * esz, hipMemcpyHostToDevice, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(d_kh + (size_t)n_vertices * esz, mean, (size_t)n_vertices * esz, hipMemcpyHostToDevice, ctx->stream));
+    double* d_part = (double*)ctx->stage_d.p;
+    PCT_TRY(pct_launch_mesh_energies(ctx, (const double*)ctx->stage_a.p, (const int*)ctx->stage_b.p, n_triangles, d_kh,
+                                     d_kh + (size_t)n_vertices * esz, curvature_is_f64 != 0, d_part, nblk, d_part + (size_t)nblk * 3));
+    PCT_HIP(ctx, hipMemcpyAsync(out3, d_part + (size_t)nblk * 3, 3 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out) {
     if (!ctx || !out) return PCT_ERR_INVALID;
     *out = ctx->tm;

@@ -126,3 +126,5 @@ int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, floa
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt);
+int pct_launch_mesh_energies(pct_ctx* ctx, const double* d_v, const int* d_tri, int64_t n_tri, const void* d_K, const void* d_H,
+                             bool f64, double* d_partial, int nblk, double* d_out);
