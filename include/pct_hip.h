@@ -136,6 +136,18 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
                       int64_t n_triangles, const void* gaussian, const void* mean, int32_t curvature_is_f64,
                       double* out3);
 
+/* ---- ingest / egress around the path (host code, no device needed) ------- */
+/* The text scans read_from_file parses with np.loadtxt (pct:51): rows x cols of whitespace-separated numbers,
+ * '#' comments and blank lines skipped.  Values are correctly rounded float64 (what Python's float() gives). */
+int pct_text_shape(const char* path, int64_t* rows, int32_t* cols);
+int pct_text_load(const char* path, int64_t rows, int32_t cols, double* out);
+/* repr(float(x)) as Python prints it -- what an f-string gives for a np.float32 widened to double -- into out32
+ * (>= 32 bytes, not NUL-terminated); returns the length. */
+int pct_format_float(double x, char* out32);
+/* The ASCII PLY of utils.py:538-551: header + one line 'x y z K H' per vertex, numbers as the reference's f-string
+ * prints them. */
+int pct_write_ply_ascii(const char* path, const float* xyz, const float* gaussian, const float* mean, int64_t n);
+
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
 /* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */

@@ -70,6 +70,10 @@ SIGNATURES = {
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
+    "pct_text_shape": (C.c_int, [C.c_char_p, _i64p, _i32p]),
+    "pct_text_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, _f64p]),
+    "pct_format_float": (C.c_int, [C.c_double, C.c_char_p]),
+    "pct_write_ply_ascii": (C.c_int, [C.c_char_p, _f32p, _f32p, _f32p, C.c_int64]),
     "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
     "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
     "pct_device_free": (C.c_int, [_p, _p]),
@@ -105,6 +109,36 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def load_text(path):
+    """np.loadtxt(path) for whitespace-separated numeric scans, multi-threaded native parser (float64 out)."""
+    lib = load()
+    rows, cols = C.c_int64(0), C.c_int32(0)
+    bpath = os.fsencode(path)
+    if lib.pct_text_shape(bpath, C.byref(rows), C.byref(cols)) != PCT_OK:
+        raise ValueError(f"cannot parse {path!r} as a rectangular table of numbers")
+    out = np.empty((rows.value, cols.value), np.float64)
+    if rows.value and lib.pct_text_load(bpath, rows.value, cols.value, _ptr(out, _f64p)) != PCT_OK:
+        raise ValueError(f"cannot parse {path!r} as a rectangular table of numbers")
+    return out
+
+
+def format_float(x):
+    """repr(float(x)) computed natively (the number format of the PLY writer)."""
+    buf = C.create_string_buffer(40)
+    n = load().pct_format_float(float(x), buf)
+    return buf.raw[:n].decode()
+
+
+def write_ply_ascii(path, points, gaussian, mean):
+    p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    g = np.ascontiguousarray(gaussian, dtype=np.float32)
+    m = np.ascontiguousarray(mean, dtype=np.float32)
+    if len(g) != len(p) or len(m) != len(p):
+        raise ValueError("one curvature value per point is required")
+    if load().pct_write_ply_ascii(os.fsencode(path), _ptr(p, _f32p), _ptr(g, _f32p), _ptr(m, _f32p), len(p)) != PCT_OK:
+        raise OSError(f"cannot write {path!r}")
 
 
 def device_count():

@@ -68,7 +68,7 @@ class PointCloud:
 
     # pct:50-66
     def read_from_file(self):
-        points = np.loadtxt(self.file_path)
+        points = _capi.load_text(self.file_path)           # np.loadtxt semantics, native multi-threaded parser
         self.points = points[:, 0:3].astype(np.float32)
         self.normals = points[:, 3:6].astype(np.float32)
         gc.collect()
@@ -181,6 +181,10 @@ class PointCloud:
         self.fit_explicit_quadratic_surfaces_to_neighborhoods()
         K, H = self.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
         return np.array(K), np.array(H)
+
+    def export_ply_with_curvatures(self, filename='output_with_curvatures.ply'):
+        """The ASCII PLY validate_shape writes after the curvature step (utils.py:538-551), same bytes."""
+        _capi.write_ply_ascii(filename, np.asarray(self.points), self.K_quadratic, self.H_quadratic)
 
     # ----------------------------------------------------------------- A10
     def explicit_quadratic_neighbor_study(self, tol=1e-7, sample_size=500, lower_bound=3, upper_bound=99):
