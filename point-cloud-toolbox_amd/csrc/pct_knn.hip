@@ -481,7 +481,10 @@ template <int R>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
-    constexpr int CAP = kStageCap * R;                 // staged stencil candidates per wave
+#ifndef PCT_STAGE_CAP2
+#define PCT_STAGE_CAP2 768
+#endif
+    constexpr int CAP = R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
     constexpr int SLOT_BITS = R == 1 ? 9 : 10;
     constexpr int KEY_BITS = 32 - SLOT_BITS;
     static_assert(CAP <= (1 << SLOT_BITS), "slot field too narrow");
