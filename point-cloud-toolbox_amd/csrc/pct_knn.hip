@@ -8,17 +8,21 @@
 // and sqrt(d2) is rounded to float32 (pct:78).  Exact-distance ties are ordered
 // by public index so the result does not depend on the cell order.
 //
-// Mapping to CDNA4: one 64-lane wave owns one occupied grid cell.  It stages the
-// 27-cell stencil once into LDS (centre row first) with coalesced 16 B/lane
-// loads, then serves every query of the cell from LDS: 64 candidates per step,
-// one fp64 distance per lane, a ballot against the running (k+1)-th distance,
-// LDS compaction of the survivors, and a wave-wide bitonic sort/merge in
-// registers (DPP row operations for lane distances 1,2,4,8; v_permlane16_swap /
-// v_permlane32_swap for 16 and 32: no LDS round trip anywhere in the network) whenever 64*R survivors are pending.  R = 1 holds
-// k+1 <= 64, R = 2 holds k+1 <= 128.  A query is finished once its (k+1)-th
-// distance is inside the radius the searched cube guarantees; otherwise the cube
-// widens shell by shell from global memory.  The query loop has ONE candidate
-// step and ONE flush site so the kernel stays small enough for the I-cache.
+// Kernels (all hand-written for gfx950, 64-lane waves):
+//   k_knn_fast   one wave = one work item (a cell and <= 12 of its owned queries).  The 27-cell stencil is staged
+//                once into LDS (12 B per candidate, centre row first, all global loads in flight together), the
+//                item's queries are prefetched into registers; per 64 candidates: fp64 distance, quantised key,
+//                ballot against the running (k+1)-th element, LDS compaction; whenever 64*R survivors are pending a
+//                wave-wide bitonic sort + merge in registers on 32-bit elements (DPP row operations for lane
+//                distances 1,2,4,8, v_permlane16_swap / v_permlane32_swap for 16 and 32: no LDS round trip in the
+//                network).  R = 1 holds k+1 <= 64, R = 2 holds k+1 <= 128.  Anything it cannot prove exact goes
+//                to the redo list.
+//   k_knn_exact  one wave = one query of the redo list (or every query, for testing): candidates cube by cube
+//                from global memory, (fp64 d2, public index) comparisons, shell-by-shell widening until the
+//                searched cube guarantees the answer.
+//   k_knn_brute  exhaustive sweep, wave per query: small clouds and the on-device cross-check.
+//   k_export*    neighbour table (sorted space, owned rows) -> public (rows, k) index / distance arrays.
+// Each kernel has ONE candidate step and ONE flush site so that it stays small enough for the I-cache.
 #include "pct_internal.h"
 
 #include <math.h>
