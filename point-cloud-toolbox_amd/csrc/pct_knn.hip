@@ -463,8 +463,9 @@ __device__ __forceinline__ void fast_level(FastK<R>& t) {
             const unsigned pk = (unsigned)lane_xor<STRIDE>((int)t.e[r]);
             const bool asc = (((lane + 64 * r) & SIZE) == 0) != DESC;
             const bool keep_min = ((lane & STRIDE) == 0) == asc;        // lane-constant: hoisted into a scalar mask
-            const bool take = (pk < t.e[r]) == keep_min;                // elements are unique (slot bits): no tie case
-            t.e[r] = take ? pk : t.e[r];
+            // elements are unique (slot bits), so min/max IS the compare-exchange; no VALU->SALU->VALU round trip
+            const unsigned lo = min(t.e[r], pk), hi = max(t.e[r], pk);
+            t.e[r] = keep_min ? lo : hi;
         }
     }
 }
