@@ -286,41 +286,54 @@ struct Sweep {
 // the closest points and the (k+1)-th distance tightens early.
 __constant__ signed char kRowOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
 
-// Wave-uniform iterator over the x-runs of the cube shell of radius `ring`
-// around cell (cx,cy,cz); ring 1 with full == true enumerates the whole 27-cell cube.
+// Iterator over the x-runs of the cube shell of radius `ring` around cell (cx,cy,cz); ring 1 with full == true
+// enumerates the whole 27-cell cube.  The run bounds of up to 64 (dz,dy) rows are fetched by the 64 lanes in
+// parallel (one memory round trip per 64 rows instead of two dependent scalar loads per row); the runs are then
+// handed out one 64-candidate step at a time, wave-uniformly.
 struct ShellIter {
-    int ring, dz, dy, part, pos, end;
+    int ring, width, nrows, row, part, pos, end, chunk;
     bool full;
+    int b_s0, b_e0, b_s1, b_e1;     // per lane: bounds of the (up to two) runs of row chunk + lane
     __device__ __forceinline__ void start(int r, bool whole_cube) {
-        ring = r; dz = -r; dy = -r; part = 0; pos = 0; end = 0; full = whole_cube;
+        ring = r; width = 2 * r + 1; nrows = width * width; row = 0; part = 0; pos = 0; end = 0; chunk = -1;
+        full = whole_cube;
+    }
+    __device__ __forceinline__ void fetch(const pct_grid& g, const int* __restrict__ cs, int cx, int cy, int cz) {
+        const int ri = chunk + lane_id();
+        b_s0 = b_e0 = b_s1 = b_e1 = 0;
+        if (ri < nrows) {
+            const int dz = ri / width - ring, dy = ri % width - ring;
+            const int z = cz + dz, y = cy + dy;
+            if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                const int base = (z * g.ny + y) * g.nx;
+                const bool face = full || dz == -ring || dz == ring || dy == -ring || dy == ring;
+                if (face) {
+                    b_s0 = cs[base + max(cx - ring, 0)];
+                    b_e0 = cs[base + min(cx + ring, g.nx - 1) + 1];
+                } else {
+                    if (cx - ring >= 0) { b_s0 = cs[base + cx - ring]; b_e0 = cs[base + cx - ring + 1]; }
+                    if (cx + ring < g.nx) { b_s1 = cs[base + cx + ring]; b_e1 = cs[base + cx + ring + 1]; }
+                }
+            }
+        }
     }
     // next 64-candidate step: returns false when the shell is exhausted
     __device__ __forceinline__ bool next(const pct_grid& g, const int* __restrict__ cs, int cx, int cy, int cz, int& base, int& lim) {
-        while (pos >= end && dz <= ring) {
-            const int z = cz + dz, y = cy + dy;
-            const bool face = full || dz == -ring || dz == ring || dy == -ring || dy == ring;
-            int s = 0, e = 0;
-            if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-                const int row = (z * g.ny + y) * g.nx;
-                if (face) {
-                    s = cs[row + max(cx - ring, 0)];
-                    e = cs[row + min(cx + ring, g.nx - 1) + 1];
-                } else if (part == 0) {
-                    if (cx - ring >= 0) { s = cs[row + cx - ring]; e = cs[row + cx - ring + 1]; }
-                } else {
-                    if (cx + ring < g.nx) { s = cs[row + cx + ring]; e = cs[row + cx + ring + 1]; }
-                }
-            }
-            if (face || part == 1) {
-                part = 0;
-                if (++dy > ring) { dy = -ring; ++dz; }
-            } else {
+        while (pos >= end) {
+            if (row >= nrows) return false;
+            if (chunk < 0 || row - chunk >= 64) { chunk = row; fetch(g, cs, cx, cy, cz); }
+            const int l = row - chunk;
+            if (part == 0) {
+                pos = __builtin_amdgcn_readlane(b_s0, l);
+                end = __builtin_amdgcn_readlane(b_e0, l);
                 part = 1;
+            } else {
+                pos = __builtin_amdgcn_readlane(b_s1, l);
+                end = __builtin_amdgcn_readlane(b_e1, l);
+                part = 0;
+                ++row;
             }
-            pos = s;
-            end = e;
         }
-        if (pos >= end) return false;
         base = pos;
         lim = end;
         pos += 64;
@@ -394,14 +407,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
         const double gz = (sw.qz - g.oz) * g.inv_cell - cz;
         ShellIter it;
         it.start(1, true);
+        // candidate loads run one step ahead of their use (a shell is many short runs, each a dependent load)
+        int nbase = 0, nlim = 0;
+        bool have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
+        float4 c_next = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
         for (;;) {
-            int base = 0, lim = 0;
-            const bool have = it.next(g, cs, cx, cy, cz, base, lim);
+            const bool have = have_next;
             if (have) {
-                const int pos = base + lane;
-                const bool valid = pos < lim;
-                float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (valid) c = a.pts[pos];
+                const int pos = nbase + lane;
+                const bool valid = pos < nlim;
+                const float4 c = c_next;
+                have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
+                if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
                 sw.consider(c, pos, valid);
                 if (sw.npend < 64 * R) continue;
             }
@@ -409,6 +427,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             if (have) continue;
             if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, it.ring)) break;
             it.start(it.ring + 1, false);
+            have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
+            if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
         }
         if (a.stats && lane == 0 && it.ring > 1) atomicAdd(&a.counters[0], 1ull);
         sw.store(row, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
@@ -910,7 +930,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     }
     // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
     {
-        const int64_t waves = exact_only ? (ctx->q_end - ctx->q_begin) : 8192;
+        const int64_t waves = exact_only ? (ctx->q_end - ctx->q_begin) : 32768;   // one query per wave for typical redo counts
         const int blocks = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
         const int* list = exact_only ? nullptr : redo;
         if (k + 1 <= 64)
