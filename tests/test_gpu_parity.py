@@ -206,6 +206,35 @@ def test_duplicate_points(gpu):
     assert (pc.dists[0:200, 0] == 0).all()
 
 
+def test_degenerate_clouds_do_not_break_the_sweep(gpu):
+    """Identical points, a line, a planar lattice: every distance ties or every stencil overflows."""
+    PC = gpu["PointCloud"]
+    same = np.tile(np.array([[0.25, -1.0, 3.0]], np.float32), (300, 1))
+    pc = PC(points=same, normals=np.zeros((300, 0)))
+    pc.plant_kdtree(10, algorithm="grid")
+    # all k+1 candidates tie at distance 0: 'drop result 0' drops the lowest index, not necessarily self (SURVEY Q2)
+    assert (pc.dists == 0).all() and (pc.neighbor_indices == np.arange(1, 11)[None, :]).all()
+    line = np.zeros((5000, 3), np.float32)
+    line[:, 0] = np.random.default_rng(0).uniform(0, 1, 5000)
+    pc = PC(points=line, normals=np.zeros((5000, 0)))
+    pc.plant_kdtree(20, algorithm="grid")
+    i, d = oracle.knn(line, 20)
+    assert np.array_equal(pc.dists, d)
+    untied = (np.diff(d, axis=1) > 0).all(1)                     # |x-a| == |x-b| happens on a line: tie order is free
+    assert untied.mean() > 0.5 and np.array_equal(pc.neighbor_indices[untied], i[untied])
+    gx, gy = np.meshgrid(np.arange(70, dtype=np.float32), np.arange(70, dtype=np.float32))
+    lattice = np.column_stack([gx.ravel(), gy.ravel(), np.zeros(4900, np.float32)])
+    pc = PC(points=lattice, normals=np.zeros((4900, 0)))
+    pc.collect_stats = True
+    pc.plant_kdtree(12, algorithm="grid")
+    _, d = oracle.knn(lattice, 12)
+    assert np.array_equal(pc.dists, d)                           # indices: ties ordered by public index
+    ex = PC(points=lattice, normals=np.zeros((4900, 0)))
+    ex.plant_kdtree(12, algorithm="brute")
+    assert np.array_equal(pc.neighbor_indices, ex.neighbor_indices)
+    assert pc.last_timings["redone_queries"] > 4000              # exact ties everywhere -> exact sweep
+
+
 # ---------------------------------------------------------- full bench size
 def test_torus_1m_sampled_oracle_and_properties(gpu, golden):
     """BASELINE config C3 at full size against the sampled reference golden G7."""
