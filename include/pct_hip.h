@@ -136,6 +136,15 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
                       int64_t n_triangles, const void* gaussian, const void* mean, int32_t curvature_is_f64,
                       double* out3);
 
+/* ---- scan preparation (next row N4) ---------------------------------------- */
+/* Voxel-grid down-sampling of convert_asc_to_ply.py:20-51: voxel = floor(coordinate / voxel_size) in float64, the
+ * first point of every voxel is kept.  indices (caller-allocated, n entries) receives the kept input indices in
+ * increasing order (= the reference's order of first occurrence), *count their number. */
+int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count);
+/* PCA surface variation of utils.py:778-829 for the loaded cloud: k_total neighbours including the point itself,
+ * out[i] = lambda_min / (lambda_0 + lambda_1 + lambda_2 + 1e-10), (owned rows) float32. */
+int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out);
+
 /* ---- ingest / egress around the path (host code, no device needed) ------- */
 /* The text scans read_from_file parses with np.loadtxt (pct:51): rows x cols of whitespace-separated numbers,
  * '#' comments and blank lines skipped.  Values are correctly rounded float64 (what Python's float() gives). */

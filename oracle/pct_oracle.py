@@ -371,3 +371,46 @@ def mesh_energies(vertices, triangles, gaussian_curvature, mean_curvature):
         fk[i] = np.mean(g[verts])
         fm2[i] = np.mean(m2[verts])
     return np.nansum(fm2 * areas), np.nansum(fk * areas), np.sum(areas)
+
+
+# --------------------------------------------------------------------------
+# N4  scan preparation.  Neither function is importable from the reference here (convert_asc_to_ply.py runs its
+# conversion at import time, utils.py needs open3d): restated from the text; parity unpinned by a reference run.
+# --------------------------------------------------------------------------
+def voxel_downsample(coordinates, voxel_size=0.1):
+    """/root/reference/convert_asc_to_ply.py:20-51."""
+    coordinates = np.array(coordinates)
+    voxel_indices = np.floor(coordinates / voxel_size).astype(np.int32)            # :34
+    voxel_dict = {}
+    for i, voxel in enumerate(voxel_indices):                                       # :39-46
+        key = tuple(voxel)
+        if key not in voxel_dict:
+            voxel_dict[key] = coordinates[i]
+    return np.array(list(voxel_dict.values()))                                      # :49
+
+
+def surface_variation(points, k_fraction=0.025, max_neighbors=100, as_written=False):
+    """/root/reference/utils.py:778-829 (estimate_curvature).
+
+    QUIRK: the reference's subscripts 'nik,njk->nij' (utils.py:822) contract the COORDINATE axis, so its "covariance"
+    is the k x k Gram matrix of the neighbourhood (rank <= 3), not the 3 x 3 covariance its comments describe.  The
+    smallest eigenvalue of that matrix is zero up to LAPACK round-off for k > 3, i.e. the function returns ~1e-9
+    noise.  ``as_written=True`` reproduces that; the default restates what the docstring and comments specify
+    (smallest / sum of the eigenvalues of the 3 x 3 covariance; both matrices have the same trace).
+    """
+    from sklearn.neighbors import NearestNeighbors
+    num_points = len(points)
+    k = min(max(5, int(k_fraction * num_points)), max_neighbors)                    # :807
+    nbrs = NearestNeighbors(n_neighbors=k).fit(points)                              # :810
+    _, indices = nbrs.kneighbors(points)                                            # :812
+    neighbors = points[indices]
+    means = neighbors.mean(axis=1, keepdims=True)                                   # :818
+    centered = neighbors - means
+    if as_written:
+        cov = np.einsum('nik,njk->nij', centered, centered) / (k - 1)               # :822 verbatim subscripts
+    else:
+        centered = centered.astype(np.float64)
+        cov = np.einsum('nki,nkj->nij', centered, centered) / (k - 1)               # the documented (dim, dim) covariance
+    eigenvalues, _ = np.linalg.eigh(cov)                                            # :825
+    sums = np.sum(eigenvalues, axis=1)
+    return eigenvalues[:, 0] / (sums + 1e-10)                                       # :828

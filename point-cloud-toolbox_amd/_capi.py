@@ -70,6 +70,8 @@ SIGNATURES = {
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
+    "pct_voxel_downsample": (C.c_int, [_p, _f64p, C.c_int64, C.c_double, _i64p, _i64p]),
+    "pct_surface_variation": (C.c_int, [_p, C.c_int32, _f32p]),
     "pct_text_shape": (C.c_int, [C.c_char_p, _i64p, _i32p]),
     "pct_text_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, _f64p]),
     "pct_format_float": (C.c_int, [C.c_double, C.c_char_p]),
@@ -294,6 +296,19 @@ class Handle:
         self._check(self._lib.pct_mesh_energies(self._h, _ptr(v, _f64p), len(v), _ptr(t, _i32p), len(t), g.ctypes.data_as(_p),
                                                m.ctypes.data_as(_p), int(f64), _ptr(out, _f64p)))
         return float(out[0]), float(out[1]), float(out[2])
+
+    def voxel_downsample(self, xyz, voxel_size):
+        p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        idx = np.empty(len(p), np.int64)
+        cnt = C.c_int64(0)
+        self._check(self._lib.pct_voxel_downsample(self._h, _ptr(p, _f64p), len(p), float(voxel_size), _ptr(idx, _i64p), C.byref(cnt)))
+        return idx[:cnt.value].copy()
+
+    def surface_variation(self, k_total):
+        out = np.empty(self.n, np.float32)
+        self._check(self._lib.pct_surface_variation(self._h, int(k_total), _ptr(out, _f32p)))
+        self.k = int(k_total) - 1
+        return out
 
     def timings(self):
         t = Timings()

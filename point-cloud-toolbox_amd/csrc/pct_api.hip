@@ -459,6 +459,35 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
     return PCT_OK;
 }
 
+int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count) {
+    PCT_TRY(begin_call(ctx));
+    if (!xyz || !indices || !count || n <= 0 || n >= 0x7F000000 || !(voxel_size > 0))
+        return pct_fail(ctx, PCT_ERR_INVALID, "bad down-sampling arguments");
+    for (int64_t i = 0; i < 3 * n; ++i)
+        if (!isfinite(xyz[i]) || fabs(xyz[i] / voxel_size) >= 2147483000.0)
+            return pct_fail(ctx, PCT_ERR_INVALID, "coordinate %lld does not map to an int32 voxel index", (long long)(i / 3));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)n * 3 * sizeof(double)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)n * sizeof(int64_t)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_voxel_downsample_device(ctx, (const double*)ctx->stage_a.p, n, voxel_size, (int64_t*)ctx->stage_b.p, count));
+    if (*count > 0) PCT_HIP(ctx, hipMemcpyAsync(indices, ctx->stage_b.p, (size_t)*count * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {
+    PCT_TRY(begin_call(ctx));
+    if (!out || k_total < 2) return pct_fail(ctx, PCT_ERR_INVALID, "bad surface-variation arguments");
+    PCT_TRY(run_knn(ctx, k_total - 1, 0.0, PCT_KNN_AUTO));            // k-1 neighbours + the point itself (utils.py:812-814)
+    const int64_t rows = ctx->q_end - ctx->q_begin;
+    PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)rows * sizeof(float)));
+    PCT_TRY(pct_launch_surface_variation(ctx, (float*)ctx->K.p));
+    PCT_HIP(ctx, hipMemcpyAsync(out, ctx->K.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_TRY(finish_knn_stats(ctx));
+    ctx->fit_valid = false;
+    return PCT_OK;
+}
+
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out) {
     if (!ctx || !out) return PCT_ERR_INVALID;
     *out = ctx->tm;
