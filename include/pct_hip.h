@@ -41,7 +41,8 @@ enum pct_knn_algo {
 typedef struct pct_timings {
     float upload_ms;          /* H2D of coordinates (0 when device-resident)            */
     float grid_ms;            /* bounding box + cell sizing + counting sort             */
-    float knn_ms;             /* neighbour sweep kernel(s) only                         */
+    float knn_ms;             /* neighbour sweep kernel(s) only (fast + exact redo)     */
+    float knn_fast_ms;        /* of which the dominant kernel k_knn_fast alone          */
     float fit_ms;             /* fused plane-align + quadric fit + curvature kernel     */
     float export_ms;          /* sorted-space -> public index translation               */
     float total_ms;

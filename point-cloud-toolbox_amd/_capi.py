@@ -28,7 +28,7 @@ KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT = 0, 1, 2, 3
 
 class Timings(C.Structure):
     _fields_ = [
-        ("upload_ms", C.c_float), ("grid_ms", C.c_float), ("knn_ms", C.c_float),
+        ("upload_ms", C.c_float), ("grid_ms", C.c_float), ("knn_ms", C.c_float), ("knn_fast_ms", C.c_float),
         ("fit_ms", C.c_float), ("export_ms", C.c_float), ("total_ms", C.c_float),
         ("knn_launches", C.c_int32), ("grid_iters", C.c_int32),
         ("cells", C.c_int64), ("occupied_cells", C.c_int64),

@@ -219,6 +219,7 @@ static int finish_knn_stats(pct_ctx* ctx) {
     ctx->tm.redone_queries = (int64_t)c[4];
     ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
     ctx->tm.knn_ms = ev_ms(ctx, 3, 4);
+    ctx->tm.knn_fast_ms = ctx->knn_sorted_space ? ev_ms(ctx, 3, 7) : 0.f;
     return PCT_OK;
 }
 

@@ -928,6 +928,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
             PCT_HIP(ctx, hipGetLastError());
         }
     }
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
     // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
     {
         const int64_t waves = exact_only ? (ctx->q_end - ctx->q_begin) : 32768;   // one query per wave for typical redo counts
