@@ -617,6 +617,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     // ceil(eps^2 * scale): the whole eps ball must be inside the guaranteed radius too
     const unsigned eps_key = eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
 
+    constexpr int NB = CAP / 64;             // candidate registers per lane: slot = b * 64 + lane
+    constexpr int LIST = 64 * R;             // capacity of the sorted list
+    unsigned t_prev = 0;                     // threshold of the previous query of this item (0 = none yet)
+
     for (int qi = 0; qi < nq; ++qi) {
         const int row = row0 + qi;
         double qx, qy, qz;
@@ -630,84 +634,89 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             qz = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
         }
 
-        FastK<R> best;
+        // ---- keys of ALL staged candidates, in registers (0xFFFFFFFF = not a candidate) ----------------------
+        unsigned key[NB];
+        int total = 0;
 #pragma unroll
-        for (int r = 0; r < R; ++r) best.e[r] = kPadElem;
-        unsigned tau = kPadElem;         // element k of best (wave-uniform)
-        int npend = 0;
-        bool empty = true;               // best holds no element yet
-        bool amb = false;                // per-lane: a key collision that could matter was seen
-
-        float cnx = 0.f, cny = 0.f, cnz = 0.f;                  // LDS reads of the next step, issued one step ahead
-        if (lane < m) { cnx = cand_x[lane]; cny = cand_y[lane]; cnz = cand_z[lane]; }
-
-        for (int base = 0;; base += 64) {
-            const bool have = base < m;
-            if (have) {
-                const int slot = base + lane;
-                const bool valid = slot < m;
-                const double dx = (double)cnx - qx, dy = (double)cny - qy, dz = (double)cnz - qz;
-                if (slot + 64 < m) { cnx = cand_x[slot + 64]; cny = cand_y[slot + 64]; cnz = cand_z[slot + 64]; }
-                const double d2 = (dx * dx + dy * dy) + dz * dz;
-                const unsigned key = min((unsigned)(d2 * scale), key_max);
-                const unsigned e = (key << SLOT_BITS) | (unsigned)slot;
-                const bool in_eps = valid && d2 < eps2;
-                const bool pass = in_eps && e < tau;
-                amb |= in_eps && ((e ^ tau) >> SLOT_BITS) == 0u;
-                const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-                if (pass) {
-                    const int at = npend + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    pend[at] = e;
+        for (int b = 0; b < NB; ++b) {
+            key[b] = 0xFFFFFFFFu;
+            if (b * 64 < m) {
+                const int slot = b * 64 + lane;
+                if (slot < m) {
+                    const double dx = (double)cand_x[slot] - qx, dy = (double)cand_y[slot] - qy, dz = (double)cand_z[slot] - qz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max);
                 }
-                npend += __popcll(mask);
+                total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
                 ++n_step;
-                if (npend < 64 * R) continue;
             }
-            if (npend > 0) {              // the ONE flush site
-                FastK<R> b;
-                wave_lds_sync();
-                const int take = npend < 64 * R ? npend : 64 * R;
+        }
+
+        // ---- threshold T with k+1 <= #(key < T) <= LIST: a few ballot-count trials.  Counts grow about linearly in
+        // d^2 (= in the key) on a surface, so a secant step from the previous query's threshold usually lands at once.
+        unsigned T = key_max + 1u;           // "everything"
+        int cnt = total;
+        bool amb = false;                    // per-lane: something this kernel cannot prove exact
+        if (total > LIST) {
+            unsigned lo = 0u, hi = key_max + 1u;          // count(lo) < k+1 ; count(hi) > LIST
+            unsigned t = t_prev ? t_prev : (unsigned)((double)(1u << KEY_BITS) / 12.1);   // first guess: one cell edge
+            const float target = 0.5f * (float)(k + 1 + LIST);
+            bool found = false;
+#pragma unroll 1
+            for (int trial = 0; trial < 16; ++trial) {
+                int c = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r;
-                    b.e[r] = i < take ? pend[i] : kPadElem;
-                }
-                const int rest = npend - take;
-                unsigned mv = 0;
-                if (lane < rest) mv = pend[take + lane];
-                wave_lds_sync();
-                if (lane < rest) pend[lane] = mv;
-                wave_lds_sync();
-                npend = rest;
-                fast_sort_from<R, 2, true>(b);                 // descending
-                if (empty) {
-                    // first batch: the running list is this batch in ascending order = lanes (and slots) reversed
+                for (int b = 0; b < NB; ++b)
+                    if (b * 64 < m) c += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] < t));
+                if (c >= k + 1 && c <= LIST) { T = t; cnt = c; found = true; break; }
+                if (c < k + 1) lo = t; else hi = t;
+                if (hi - lo <= 1u) break;                  // a pile of equal keys straddles the window
+                const float guess = (float)t * target / (float)(c > 0 ? c : 1);
+                unsigned nt = guess >= 4294967040.f ? hi : (unsigned)guess;
+                if (c == 0) nt = t * 4u > t ? t * 4u : hi;
+                if (nt <= lo || nt >= hi) nt = lo + (hi - lo) / 2u;
+                t = nt;
+            }
+            amb |= !found;
+        }
+        t_prev = T <= key_max ? T : t_prev;
+
+        // ---- compact the selected candidates (all of them when there are <= LIST) and sort them ONCE ----------
+        FastK<R> best;
+        {
+            int base = 0;
+            wave_lds_sync();
 #pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        int v = __builtin_amdgcn_mov_dpp((int)b.e[R - 1 - r], 0x140, 0xF, 0xF, true);   // row_mirror
-                        v = lane_xor<16>(v);
-                        best.e[r] = (unsigned)lane_xor<32>(v);
+            for (int b = 0; b < NB; ++b) {
+                if (b * 64 < m) {
+                    const bool pass = key[b] < T;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                    if (pass) {
+                        const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (at < LIST) pend[at] = (key[b] << SLOT_BITS) | (unsigned)(b * 64 + lane);
                     }
-                    empty = false;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) best.e[r] = min(b.e[r], best.e[r]);
-                    fast_strides<R, 64 * R, 32 * R, false>(best);
+                    base += (int)__popcll(mask);
                 }
-                // threshold = element k; the tail beyond it must not share its key
-                {
-                    const int sl = k >> 6, src = k & 63;
-                    unsigned v = best.e[0];
-#pragma unroll
-                    for (int r = 1; r < R; ++r)
-                        if (sl == r) v = best.e[r];
-                    tau = (unsigned)__builtin_amdgcn_readlane((int)v, src);
-                    const unsigned last = (unsigned)__builtin_amdgcn_readlane((int)best.e[R - 1], 63);
-                    amb |= tau != kPadElem && last != kPadElem && ((last ^ tau) >> SLOT_BITS) == 0u;
-                }
-                ++n_flush;
             }
-            if (!have) break;
+            wave_lds_sync();
+            const int have = cnt < LIST ? cnt : LIST;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int i = lane + 64 * r;
+                best.e[r] = i < have ? pend[i] : kPadElem;
+            }
+            wave_lds_sync();
+            fast_sort_from<R, 2, false>(best);             // ascending
+            ++n_flush;
+        }
+        unsigned tau;                        // element k of the list = the (k+1)-th nearest (padding if fewer exist)
+        {
+            const int sl = k >> 6, src = k & 63;
+            unsigned v = best.e[0];
+#pragma unroll
+            for (int r = 1; r < R; ++r)
+                if (sl == r) v = best.e[r];
+            tau = (unsigned)__builtin_amdgcn_readlane((int)v, src);
         }
 
         // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up; all in key units)
