@@ -320,8 +320,9 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     float bbox[6];
     PCT_TRY(pct_pack_points(ctx, bbox));
 
-    // measured optimum on surface clouds: 0.5 with one list slot per lane (k+1 <= 64), 0.45 with two
-    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 64 ? 0.5 : 0.45);
+    // measured optima on surface clouds (tools/tune_factor.py): larger cells cost candidates, smaller ones cost
+    // trips to the exact sweep; the LDS staging capacity caps the large side
+    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 32 ? 0.65 : k + 1 <= 64 ? 0.55 : 0.45);
     const double target = factor * (k + 1);
     const int64_t cell_cap = (int64_t)1 << 27;
 

@@ -31,7 +31,7 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 #ifndef PCT_STAGE_CAP
-#define PCT_STAGE_CAP 448
+#define PCT_STAGE_CAP 512
 #endif
 constexpr int kStageCap = PCT_STAGE_CAP;   // LDS-staged stencil candidates per wave and per 64 list slots (12 B each, SoA)
 
