@@ -16,9 +16,8 @@
 //           eigenvalue (== Vt[-1], pct:283) -> sign flip by far-minus-near
 //           neighbour (pct:286-297) -> Rodrigues rotation to +z (pct:300-312)
 //   pass 2  rotate (pct:315), round to float32 (pct:350), float32 design row
-//           [a^2,b^2,ab,a,b,1] (pct:358), fp64 normal equations with columns
-//           scaled by a power of two of the neighbourhood radius (exact),
-//           Cholesky solve, coefficients rounded to float32 (pct:359)
+//           [a^2,b^2,ab,a,b,1] (pct:358), fp64 normal equations, Cholesky
+//           solve, coefficients rounded to float32 (pct:359)
 //   then    K, H, H^2 in float32 arithmetic in the reference's operation order
 //           (pct:403-422).
 // Compiled with -ffp-contract=off so the float32 sequences are not fused.
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     }
 
     // ---- pass 1: moments of the centred neighbourhood ---------------------
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0, r2max = 0;
+    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
     double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
     // gathers are issued four neighbours ahead of their use (the row walk is latency-bound otherwise)
 #define PASS1_ACC(x, y, z)                                                          \
@@ -223,7 +222,6 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         sx += x; sy += y; sz += z;                                                  \
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);           \
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);           \
-        r2max = fmax(r2max, (x * x + y * y) + z * z);                               \
     } while (0)
     {
         int j = 0;
@@ -250,9 +248,9 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     const double r00 = rot[0], r01 = rot[1], r02 = rot[2], r10 = rot[3], r11 = rot[4], r12 = rot[5], r20 = rot[6], r21 = rot[7], r22 = rot[8];
 
     // ---- pass 2: float32 design rows -> scaled fp64 normal equations --------
-    int e2 = 0;
-    if (r2max > 0) { int ex; frexp(sqrt(r2max), &ex); e2 = -ex; }   // radius * 2^e2 in [0.5, 1)
-    const double s1 = ldexp(1.0, e2), s2 = ldexp(1.0, 2 * e2);
+    // No column scaling: scaling the Gram matrix by powers of two commutes with every rounding of an unpivoted
+    // Cholesky solve, so it cannot change a single bit of the result (only the overflow/underflow range, which fp64
+    // covers down to neighbourhood radii of ~1e-70).
     double g[21];
     double b[6];
 #pragma unroll
@@ -265,11 +263,11 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         const float pb = (float)((r10 * x + r11 * y) + r12 * z);                    \
         const float pz = (float)((r20 * x + r21 * y) + r22 * z);                    \
         double c[6];                                                                \
-        c[0] = (double)(pa * pa) * s2;                                              \
-        c[1] = (double)(pb * pb) * s2;                                              \
-        c[2] = (double)(pa * pb) * s2;                                              \
-        c[3] = (double)pa * s1;                                                     \
-        c[4] = (double)pb * s1;                                                     \
+        c[0] = (double)(pa * pa);                                                   \
+        c[1] = (double)(pb * pb);                                                   \
+        c[2] = (double)(pa * pb);                                                   \
+        c[3] = (double)pa;                                                          \
+        c[4] = (double)pb;                                                          \
         c[5] = 1.0;                                                                 \
         const double zz = (double)pz;                                               \
         int t = 0;                                                                  \
@@ -329,8 +327,8 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         b[i] = s * dinv[i];
     }
 #undef GI
-    const float A = (float)(b[0] * s2), B = (float)(b[1] * s2), C = (float)(b[2] * s2);
-    const float D = (float)(b[3] * s1), E = (float)(b[4] * s1), F = (float)b[5];
+    const float A = (float)b[0], B = (float)b[1], C = (float)b[2];
+    const float D = (float)b[3], E = (float)b[4], F = (float)b[5];
     float* co = a.coefs + out * 6;
     co[0] = A; co[1] = B; co[2] = C; co[3] = D; co[4] = E; co[5] = F;
 
