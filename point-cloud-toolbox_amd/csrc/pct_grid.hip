@@ -11,6 +11,7 @@
 #include "pct_internal.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -339,7 +340,8 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
     const bool sharded = ctx->q_begin > 0 || ctx->q_end < n;             // some points are candidates only
-    const int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
+    int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
+    if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
     int nblk = 0;
     pct_grid g = {};
