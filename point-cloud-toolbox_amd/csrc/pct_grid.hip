@@ -343,11 +343,20 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
     if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
+    const int64_t n_owned = ctx->q_end - ctx->q_begin;
+    PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
+    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)n * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, (size_t)n_owned * sizeof(int)));
+    if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
     int nblk = 0;
     pct_grid g = {};
     double a_prev = 0, m_prev = 0;
     int iters = 0;
     const int max_iter = 6;
+    int4 tot = make_int4(0, 0, 0, 0);
+    // Every pass runs the whole build (histogram, scan, scatter) and only then reads back the occupancy statistic
+    // together with the scan totals: the first cell size is accepted in the common case, which then costs ONE host
+    // synchronisation instead of two; a rejected size costs a speculative scatter.
     for (int it = 0; it < max_iter; ++it) {
         if (eps > 0 && a > eps * 1.000001) a = eps * 1.000001;   // one ring already covers the eps ball
         set_dims(&g, bbox, a);
@@ -367,12 +376,26 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4)));
+        PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
+        PCT_TRY(pct_reserve(ctx, &ctx->own_start, (size_t)(g.ncell + 1) * sizeof(int)));
+        PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n_owned < g.ncell ? n_owned : g.ncell) + (size_t)n_owned / items_q + 16) * sizeof(int2)));
         hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (int4*)ctx->scan_tmp.p, (unsigned long long*)ctx->red.p);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk);
+        hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+                           (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
+                           (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
+        hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
+                           (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
+                           (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
+                           (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
+                           ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
+                           ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
         PCT_HIP(ctx, hipGetLastError());
         unsigned long long s2 = 0;
         PCT_HIP(ctx, hipMemcpyAsync(&s2, ctx->red.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PCT_HIP(ctx, hipMemcpyAsync(&tot, (int4*)ctx->scan_tmp.p + nblk, sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
         PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ++iters;
         double m = (double)s2 / (double)n;
@@ -397,33 +420,6 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->tm.grid_iters = iters;
     ctx->tm.cells = g.ncell;
     ctx->tm.cell_size = g.cell;
-
-    // rest of the exclusive scan + ordered work-item list
-    const int64_t n_owned = ctx->q_end - ctx->q_begin;
-    PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->own_start, (size_t)(g.ncell + 1) * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n_owned < g.ncell ? n_owned : g.ncell) + (size_t)n_owned / items_q + 16) * sizeof(int2)));
-    hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
-                       (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
-                       (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
-    PCT_HIP(ctx, hipGetLastError());
-    int4 tot;
-    PCT_HIP(ctx, hipMemcpyAsync(&tot, (int4*)ctx->scan_tmp.p + nblk, sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
-
-    // counting-sort scatter
-    PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
-    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)n * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, (size_t)n_owned * sizeof(int)));
-    if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
-    hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                       (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
-                       (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
-                       (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
-                       ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
-                       ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
-    PCT_HIP(ctx, hipGetLastError());
-    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (tot.x != n || tot.z != n_owned)
         return pct_fail(ctx, PCT_ERR_INVALID, "cell scan totals %d/%d != %lld/%lld", tot.x, tot.z, (long long)n, (long long)n_owned);
     ctx->n_items = tot.y;
