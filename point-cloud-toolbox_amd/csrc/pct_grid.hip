@@ -141,8 +141,9 @@ __device__ __forceinline__ int4 cell_counts(const int* __restrict__ own, const i
 // first pass: per-tile sums; also accumulates sum_c count_c^2 (= sum over points of the population of
 // their own cell), the statistic the cell-size loop steers on
 __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ own, const int* __restrict__ oth, int64_t ncell, int items_q,
-                                                      int4* __restrict__ tmp, unsigned long long* __restrict__ sumsq) {
+                                                      int4* __restrict__ tmp, unsigned long long* __restrict__ sq_part) {
     __shared__ int4 sh[kBlock / 64];
+    __shared__ unsigned long long shq[kBlock / 64];
     unsigned long long sq = 0;
     int64_t base = (int64_t)blockIdx.x * kScanTile + (int64_t)threadIdx.x * kScanItems;
     int4 v = make_int4(0, 0, 0, 0);
@@ -157,20 +158,32 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ ow
     }
     if ((threadIdx.x & 63) == 0) {
         sh[threadIdx.x >> 6] = v;
-        if (sq) atomicAdd(sumsq, sq);
+        shq[threadIdx.x >> 6] = sq;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         int4 t = make_int4(0, 0, 0, 0);
-        for (int i = 0; i < kBlock / 64; ++i) t = add3(t, sh[i]);
+        unsigned long long q = 0;
+        for (int i = 0; i < kBlock / 64; ++i) { t = add3(t, sh[i]); q += shq[i]; }
         tmp[blockIdx.x] = t;
+        sq_part[blockIdx.x] = q;        // per-tile partial: no same-address atomics (they serialise at ~88/us)
     }
 }
 
 // single block: exclusive scan of the per-tile sums; totals to tmp[nblk]
-__global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int nblk) {
+__global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int nblk, const unsigned long long* __restrict__ sq_part,
+                                                      unsigned long long* __restrict__ sumsq) {
     __shared__ int4 sh[1024];
     __shared__ int4 carry;
+    __shared__ unsigned long long shq[16];
+    {   // sum of the per-tile sum-of-squares partials
+        unsigned long long q = 0;
+        for (int i = threadIdx.x; i < nblk; i += 1024) q += sq_part[i];
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        if ((threadIdx.x & 63) == 0) shq[threadIdx.x >> 6] = q;
+        __syncthreads();
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += shq[i]; *sumsq = t; }
+    }
     if (threadIdx.x == 0) carry = make_int4(0, 0, 0, 0);
     __syncthreads();
     for (int base = 0; base < nblk; base += 1024) {
@@ -375,14 +388,16 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            (const float4*)ctx->pts4.p, n, g, (int)ctx->q_begin, (int)ctx->q_end, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
-        PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4)));
+        PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
+        unsigned long long* sq_part = (unsigned long long*)((int4*)ctx->scan_tmp.p + nblk + 1);
         PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
         PCT_TRY(pct_reserve(ctx, &ctx->own_start, (size_t)(g.ncell + 1) * sizeof(int)));
         PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n_owned < g.ncell ? n_owned : g.ncell) + (size_t)n_owned / items_q + 16) * sizeof(int2)));
         hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
-                           (int4*)ctx->scan_tmp.p, (unsigned long long*)ctx->red.p);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk);
+                           (int4*)ctx->scan_tmp.p, sq_part);
+        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
+                           (const unsigned long long*)sq_part, (unsigned long long*)ctx->red.p);
         hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
