@@ -396,6 +396,35 @@ def test_config_c5_bunny_tiled_20m_eps(gpu, golden):
     h.close()
 
 
+def test_validate_shape_call_sequence(gpu, tmp_path):
+    """The one production caller (utils.py:481-501): file ctor -> plant(100) -> study -> fit -> re-plant -> curvatures.
+    The second planting does NOT influence the curvatures: they come from the k=100 fit."""
+    pts = gpu["shapes"].torus_random(6000, seed=17)
+    f = tmp_path / "verts.txt"
+    np.savetxt(f, pts.astype(np.float64))                       # utils.py:372-374 writes the vertices with np.savetxt
+    pcl = gpu["PointCloud"](str(f))                              # utils.py:481
+    pcl.plant_kdtree(k_neighbors=100)                            # :484
+    np.random.seed(3)
+    converged = pcl.explicit_quadratic_neighbor_study()          # :487
+    pcl.fit_explicit_quadratic_surfaces_to_neighborhoods()       # :495
+    pcl.plant_kdtree(k_neighbors=converged)                      # :498
+    K, H = pcl.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()   # :501
+    shifted = pts.copy()
+    shifted[:, 0] -= shifted[:, 0].max()
+    shifted[:, 1] -= shifted[:, 1].max()
+    assert np.array_equal(pcl.points, shifted)
+    ref = oracle.pipeline_batched(shifted, 100)
+    assert_curvature(K, H, ref["K"], ref["H"])
+    np.random.seed(3)
+    ref_conv, _ = oracle.neighbor_study(shifted, np.random.randint(0, 6000, 500))
+    assert converged == ref_conv
+    assert len(K) == 6000 and not np.isnan(K).any() and pcl.k_neighbors == converged
+    out = tmp_path / "out.ply"
+    pcl.export_ply_with_curvatures(str(out))                      # utils.py:538-551
+    lines = out.read_text().splitlines()
+    assert lines[2] == "element vertex 6000" and lines[9] == f"{shifted[0][0]} {shifted[0][1]} {shifted[0][2]} {K[0]} {H[0]}"
+
+
 # ------------------------------------------------- next row N1: neighbour study
 def test_neighbor_study_matches_reference_golden(gpu, golden):
     """explicit_quadratic_neighbor_study (pct:732-800) with the reference's own seeded draw (G8)."""
