@@ -47,6 +47,11 @@ class PointCloud:
         self._nbr_cache = None
         self._user_neighbors = None
         self._fit_on_device = False
+        self._coefs_cache = None
+        self._user_coefs = None
+        self._device_curv = None
+        self._plant_token = 0
+        self._fit_token = -1
         self.eps = None
         self.collect_stats = False      # sweep statistics in last_timings (costs atomics)
 
@@ -114,10 +119,15 @@ class PointCloud:
         self.eps = eps
         algo = _ALGORITHMS[algorithm]
         h = self._ctx()
+        if self._fit_on_device and self._user_coefs is None:
+            # the reference keeps the fitted coefficients across a re-planting (utils.py:495-501):
+            # bring them to the host before the device results are invalidated
+            self._user_coefs = self.quadratic_coefficients
         h.knn(k_neighbors, eps or 0.0, algo)
         self._nbr_cache = None
         self._user_neighbors = None
         self._fit_on_device = False
+        self._plant_token += 1
         self.last_timings = h.timings()
 
     def _download_neighbors(self):
@@ -157,18 +167,38 @@ class PointCloud:
             h.fit_indices(self._user_neighbors)
         else:
             h.fit()                                          # AttributeError if no table (pct:640)
-        coefs, K, H, H2 = h.get_fit(0, self.num_points)
-        self.quadratic_coefficients = coefs
-        self._device_curv = (K, H, H2)
+        # results stay on the device: coefficients (24 B/point) are downloaded on first access, K/H/H^2 by
+        # calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
+        self._coefs_cache = None
+        self._user_coefs = None
+        self._device_curv = None
         self._fit_on_device = True
+        self._fit_token = self._plant_token
         self.last_timings = h.timings()
+
+    @property
+    def quadratic_coefficients(self):
+        """(N, 6) float32 [A, B, C, D, E, F] per point (pct:637-647), fetched from the device on first access."""
+        if self._user_coefs is not None:
+            return self._user_coefs
+        if not self._fit_on_device:
+            raise AttributeError("'PointCloud' object has no attribute 'quadratic_coefficients'")
+        if self._coefs_cache is None:
+            self._coefs_cache = self._handle.get_fit(0, self.num_points, K=False, H=False, H2=False)[0]
+        return self._coefs_cache
+
+    @quadratic_coefficients.setter
+    def quadratic_coefficients(self, value):
+        self._user_coefs = value
 
     # ------------------------------------------------------------------ A8
     def calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points(self):
         """K, H, H^2 from the fitted coefficients (pct:657-674)."""
-        if self._fit_on_device and self._device_curv is not None:
-            K, H, H2 = self._device_curv                     # produced by the fused kernel
-        else:
+        if self._user_coefs is None and self._fit_on_device and self._handle is not None:
+            if self._device_curv is None:                    # produced by the fused kernel, still on the device
+                self._device_curv = self._handle.get_fit(0, self.num_points, coefs=False)[1:]
+            K, H, H2 = self._device_curv
+        else:                                                # coefficients the caller supplied, or a re-planted table
             K, H, H2 = self._ctx().curvatures_from_coefficients(np.asarray(self.quadratic_coefficients))
         self.K_quadratic = K
         self.H_quadratic = H
@@ -236,6 +266,9 @@ class PointCloud:
         self._user_neighbors = None
         _, K, H, H2 = h.get_fit(0, self.num_points, coefs=False)
         self.K_quadratic, self.H_quadratic, self.K_H_sq_quadratic = K, H, H2
+        self._plant_token += 1
+        self._fit_token = self._plant_token
+        self._fit_on_device, self._user_coefs, self._coefs_cache, self._device_curv = True, None, None, (K, H, H2)
         self.last_timings = h.timings()
         return K, H
 
