@@ -2,7 +2,7 @@
 
 Workload (config.workload): synthetic torus R=1, r=1/3, random (theta, phi), seed 1234, float32,
 1 000 000 points PER GPU at k=50 (BASELINE configs[2]; weak scaling: N ranks hold an N-million-point
-torus, rank r owns index range r).  One "step" = one full pass of the hot path over the resident
+torus in scan order, rank r owns index range r = the r-th major-angle wedge).  One "step" = one full pass of the hot path over the resident
 cloud: [N>1: RCCL all-gather of the coordinate shards] -> cell-list build -> k-NN sweep -> fused
 plane-align / quadric fit / K,H.  Inputs are in HBM when the timed region starts.
 
@@ -99,7 +99,14 @@ def main():
     k = args.k
     n_total = args.points_per_gpu * world
     lo, hi = shard_range(n_total, rank, world)
-    local = shapes.torus_random(n_total, seed=1234, lo=lo, hi=hi)
+    if world == 1:
+        local = shapes.torus_random(n_total, seed=1234)
+        order = "random (theta,phi) seed 1234"
+    else:
+        # multi-GPU clouds arrive in scan order (the reference's own generator is theta-major, utils.py:888-891):
+        # rank r's index range is the r-th major-angle wedge, random inside it
+        local = shapes.torus_scan_order(n_total, world, rank, seed=1234)
+        order = f"random (theta,phi) seed 1234 in scan order ({world} major-angle wedges = the index-range shards)"
 
     if dist is not None:
         torch.cuda.set_device(local_rank)
@@ -165,11 +172,12 @@ def main():
             "ms_per_step": 1e3 * dt / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"synthetic torus R=1 r=1/3, random (theta,phi) seed 1234, float32, "
+            "config": {"workload": f"synthetic torus R=1 r=1/3, {order}, float32, "
                                    f"{args.points_per_gpu} points per GPU ({n_total} total), k={k}, grid k-NN + "
                                    "fused plane-align/quadric-fit/curvature (BASELINE configs[2])",
                        "points_total": n_total, "k": k,
-                       "parallelism": f"point-index-range shards x{world}" + (" + RCCL all-gather of coordinates" if world > 1 else "")},
+                       "parallelism": f"point-index-range shards x{world}" + (" + RCCL all-gather of coordinates, each rank "
+                                      "keeps the points near its range" if world > 1 else "")},
             "roofline": {"bound": "hbm", "kernel": "k_knn_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(nq, k),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_ms / steps},

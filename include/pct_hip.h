@@ -56,6 +56,12 @@ typedef struct pct_timings {
     int64_t candidate_steps;  /* 64-candidate distance steps of the sweep               */
     int64_t redone_queries;   /* queries re-done by the exact sweep (float-key collisions) */
     double cell_size;
+    int64_t grid_points;      /* points held by the cell list: the cloud, or (sharded handles) the part of it
+                                 near the owned range                                    */
+    int32_t limit_retries;    /* 1 = the sweep was repeated with every point because a query reached past
+                                 the part kept                                            */
+    int32_t reserved_;
+    double occupancy;         /* mean number of points sharing a point's cell (the cell-size search steers on it) */
 } pct_timings;
 
 /* ---- lifetime ---------------------------------------------------------- */

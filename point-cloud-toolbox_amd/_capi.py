@@ -35,6 +35,8 @@ class Timings(C.Structure):
         ("ring_fallbacks", C.c_int64), ("lds_overflows", C.c_int64),
         ("flushes", C.c_int64), ("candidate_steps", C.c_int64), ("redone_queries", C.c_int64),
         ("cell_size", C.c_double),
+        ("grid_points", C.c_int64), ("limit_retries", C.c_int32), ("reserved_", C.c_int32),
+        ("occupancy", C.c_double),
     ]
 
     def as_dict(self):

@@ -76,6 +76,11 @@ int pct_create(int device, pct_ctx** out) {
             delete ctx;
             return PCT_ERR_HIP;
         }
+    if (hipHostMalloc((void**)&ctx->pin, 4096, hipHostMallocMapped) != hipSuccess) {
+        delete ctx;
+        return PCT_ERR_OOM;
+    }
+    memset(ctx->pin, 0, 4096);
     *out = ctx;
     return PCT_OK;
 }
@@ -89,6 +94,7 @@ void pct_destroy(pct_ctx* ctx) {
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
                       &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
     for (pct_buf* b : all) release(b);
+    if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -111,6 +117,8 @@ static int new_cloud(pct_ctx* ctx, int64_t n) {
     ctx->q_end = n;
     ctx->grid_valid = ctx->knn_valid = ctx->fit_valid = ctx->pts4_valid = false;
     ctx->has_f64 = false;
+    ctx->no_cull = ctx->culled = false;
+    ctx->retries = 0;
     ctx->tm = pct_timings{};
     return PCT_OK;
 }
@@ -160,6 +168,8 @@ int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end) {
     ctx->q_begin = begin;
     ctx->q_end = end;
     ctx->knn_valid = ctx->fit_valid = ctx->grid_valid = false;   // the cell order depends on the owned range
+    ctx->no_cull = false;
+    ctx->retries = 0;
     return PCT_OK;
 }
 
@@ -195,6 +205,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         PCT_TRY(pct_pack_points(ctx, bbox));
         ctx->tm.grid_iters = 0;
         ctx->tm.cells = ctx->tm.occupied_cells = 0;
+        ctx->tm.grid_points = ctx->n;
         ctx->tm.cell_size = 0;
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
@@ -208,9 +219,9 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     return PCT_OK;
 }
 
-static int finish_knn_stats(pct_ctx* ctx) {
-    unsigned long long c[5] = {0, 0, 0, 0, 0};
-    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
+    unsigned long long* c = (unsigned long long*)(ctx->pin + 192);       // pinned: a plain DMA, no staging
+    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.ring_fallbacks = (int64_t)c[0];
     ctx->tm.lds_overflows = (int64_t)c[1];
@@ -220,13 +231,23 @@ static int finish_knn_stats(pct_ctx* ctx) {
     ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
     ctx->tm.knn_ms = ev_ms(ctx, 3, 4);
     ctx->tm.knn_fast_ms = ctx->knn_sorted_space ? ev_ms(ctx, 3, 7) : 0.f;
+    // a sharded handle that left far points out of its grid met a query those points could matter to
+    *beyond_limits = ctx->knn_sorted_space && ctx->culled && c[5] > 0;
+    ctx->tm.limit_retries = ctx->retries;
     return PCT_OK;
 }
 
 int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     PCT_TRY(begin_call(ctx));
+    bool again = false;
     PCT_TRY(run_knn(ctx, k, eps, algo));
-    PCT_TRY(finish_knn_stats(ctx));
+    PCT_TRY(finish_knn_stats(ctx, &again));
+    if (again) {                      // rare: redo with every point in the grid
+        ctx->no_cull = true;
+        ctx->retries = 1;
+        PCT_TRY(run_knn(ctx, k, eps, algo));
+        PCT_TRY(finish_knn_stats(ctx, &again));
+    }
     ctx->tm.fit_ms = 0;
     ctx->tm.total_ms = ev_ms(ctx, 2, 4);
     return PCT_OK;
@@ -247,11 +268,17 @@ int pct_fit(pct_ctx* ctx) {
 
 int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     PCT_TRY(begin_call(ctx));
-    PCT_TRY(run_knn(ctx, k, eps, algo));
-    PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
-    PCT_TRY(pct_launch_fit_table(ctx));
-    PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
-    PCT_TRY(finish_knn_stats(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool again = false;
+        PCT_TRY(run_knn(ctx, k, eps, algo));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+        PCT_TRY(pct_launch_fit_table(ctx));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+        PCT_TRY(finish_knn_stats(ctx, &again));
+        if (!again) break;
+        ctx->no_cull = true;          // rare: redo with every point in the grid
+        ctx->retries = 1;
+    }
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
@@ -404,7 +431,7 @@ int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int6
             free(h_pos);
             return pct_fail(ctx, PCT_ERR_INVALID, "sample row %lld outside the owned range", (long long)sample_rows[i]);
         }
-        h_pos[i] = (int)(sample_rows[i] - (ctx->knn_sorted_space ? 0 : ctx->q_begin));   // exhaustive table: row = index - q_begin
+        h_pos[i] = (int)(sample_rows[i] - ctx->q_begin);    // exhaustive table: that is the row; grid table: index into row_of
     }
     const int32_t pitch = (n_hi + 1 + 3) & ~3;
     int st = pct_reserve(ctx, &ctx->stage_c, (size_t)n_samples * sizeof(int));
@@ -479,12 +506,18 @@ int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxe
 int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {
     PCT_TRY(begin_call(ctx));
     if (!out || k_total < 2) return pct_fail(ctx, PCT_ERR_INVALID, "bad surface-variation arguments");
-    PCT_TRY(run_knn(ctx, k_total - 1, 0.0, PCT_KNN_AUTO));            // k-1 neighbours + the point itself (utils.py:812-814)
     const int64_t rows = ctx->q_end - ctx->q_begin;
-    PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)rows * sizeof(float)));
-    PCT_TRY(pct_launch_surface_variation(ctx, (float*)ctx->K.p));
-    PCT_HIP(ctx, hipMemcpyAsync(out, ctx->K.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    PCT_TRY(finish_knn_stats(ctx));
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        bool again = false;
+        PCT_TRY(run_knn(ctx, k_total - 1, 0.0, PCT_KNN_AUTO));        // k-1 neighbours + the point itself (utils.py:812-814)
+        PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)rows * sizeof(float)));
+        PCT_TRY(pct_launch_surface_variation(ctx, (float*)ctx->K.p));
+        PCT_HIP(ctx, hipMemcpyAsync(out, ctx->K.p, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PCT_TRY(finish_knn_stats(ctx, &again));
+        if (!again) break;
+        ctx->no_cull = true;
+        ctx->retries = 1;
+    }
     ctx->fit_valid = false;
     return PCT_OK;
 }

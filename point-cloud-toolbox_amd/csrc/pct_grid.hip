@@ -26,7 +26,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// red layout: [0..5] = min xyz, max xyz as ordered ints ; [6] = non-finite flag
+// Reduction record of the packing passes (device memory, ctx->red).
+struct PackRed {
+    int bb[6];                 // min xyz, max xyz as ordered ints
+    int bad;                   // a non-finite coordinate was seen
+    int g_begin;               // compacted position of the first owned point (cull pass)
+    double s[3], ss[3];        // sums / sums of squares of (coordinate - shift): drives the outlier-trimmed grid box
+    unsigned long long cnt;    // points accumulated
+};
+
 __device__ __forceinline__ int float_order(float f) {
     int i = __float_as_int(f);
     return i >= 0 ? i : i ^ 0x7fffffff;
@@ -42,44 +50,276 @@ __host__ __device__ __forceinline__ float order_float(int i) {
 #endif
 }
 
-__global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ xyz, int64_t n,
-                                                 float4* __restrict__ pts4, int* __restrict__ red) {
-    float mn[3] = {INFINITY, INFINITY, INFINITY};
-    float mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    int bad = 0;
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        bad |= !(isfinite(x) && isfinite(y) && isfinite(z));
-        pts4[i] = make_float4(x, y, z, __int_as_float((int)i));
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// Per-thread accumulator of the packing passes; commit() folds a block into its own PackRed record.
+struct PackAcc {
+    float mn[3], mx[3];
+    double s[3], ss[3];
+    int bad;
+    unsigned cnt;
+    __device__ void init() {
+        for (int a = 0; a < 3; ++a) { mn[a] = INFINITY; mx[a] = -INFINITY; s[a] = 0; ss[a] = 0; }
+        bad = 0;
+        cnt = 0;
+    }
+    __device__ void add(float x, float y, float z, const float* sh) {
         mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
         mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        const double dx = (double)x - sh[0], dy = (double)y - sh[1], dz = (double)z - sh[2];
+        s[0] += dx; ss[0] += dx * dx;
+        s[1] += dy; ss[1] += dy * dy;
+        s[2] += dz; ss[2] += dz * dz;
+        ++cnt;
     }
-    __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
-    __shared__ int s_bad[kBlock / 64];
-    for (int a = 0; a < 3; ++a) {
-        mn[a] = wave_min(mn[a]);
-        mx[a] = wave_max(mx[a]);
+    __device__ void commit(PackRed* part) {      // this block's record (plain stores)
+        __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
+        __shared__ double s_s[kBlock / 64][3], s_ss[kBlock / 64][3];
+        __shared__ int s_bad[kBlock / 64];
+        __shared__ unsigned s_cnt[kBlock / 64];
+        for (int a = 0; a < 3; ++a) {
+            mn[a] = wave_min(mn[a]);
+            mx[a] = wave_max(mx[a]);
+            s[a] = wave_sum(s[a]);
+            ss[a] = wave_sum(ss[a]);
+        }
+        bad = __any(bad);
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+        const int w = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) {
+            for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; s_s[w][a] = s[a]; s_ss[w][a] = ss[a]; }
+            s_bad[w] = bad;
+            s_cnt[w] = cnt;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            const int a = threadIdx.x;
+            float lo = s_mn[0][a], hi = s_mx[0][a];
+            double t = s_s[0][a], tt = s_ss[0][a];
+            for (int i = 1; i < kBlock / 64; ++i) {
+                lo = fminf(lo, s_mn[i][a]); hi = fmaxf(hi, s_mx[i][a]);
+                t += s_s[i][a]; tt += s_ss[i][a];
+            }
+            part->bb[a] = float_order(lo);
+            part->bb[3 + a] = float_order(hi);
+            part->s[a] = t;
+            part->ss[a] = tt;
+        }
+        if (threadIdx.x == 3) {
+            int b = 0;
+            unsigned c = 0;
+            for (int i = 0; i < kBlock / 64; ++i) { b |= s_bad[i]; c += s_cnt[i]; }
+            part->bad = b;
+            part->cnt = c;
+        }
     }
-    bad = __any(bad);
-    const int w = threadIdx.x >> 6;
+};
+
+// second stage of every packing pass: folds the per-block records into the handle's PackRed.  (Atomics from
+// every block onto one cache line cost more than the pass itself.)
+__global__ __launch_bounds__(kBlock) void k_pack_final(const PackRed* __restrict__ parts, int n_parts, PackRed* __restrict__ red,
+                                                       PackRed* __restrict__ host_copy) {
+    __shared__ PackRed sh[kBlock / 64];
+    int bb[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
+    double s[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
+    int bad = 0;
+    unsigned long long cnt = 0;
+    for (int i = threadIdx.x; i < n_parts; i += kBlock) {
+        const PackRed p = parts[i];
+        for (int a = 0; a < 3; ++a) {
+            bb[a] = min(bb[a], p.bb[a]);
+            bb[3 + a] = max(bb[3 + a], p.bb[3 + a]);
+            s[a] += p.s[a];
+            ss[a] += p.ss[a];
+        }
+        bad |= p.bad;
+        cnt += p.cnt;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        for (int a = 0; a < 3; ++a) {
+            bb[a] = min(bb[a], __shfl_xor(bb[a], o));
+            bb[3 + a] = max(bb[3 + a], __shfl_xor(bb[3 + a], o));
+            s[a] += __shfl_xor(s[a], o);
+            ss[a] += __shfl_xor(ss[a], o);
+        }
+        bad |= __shfl_xor(bad, o);
+        cnt += __shfl_xor(cnt, o);
+    }
     if ((threadIdx.x & 63) == 0) {
-        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
-        s_bad[w] = bad;
+        PackRed& w = sh[threadIdx.x >> 6];
+        for (int a = 0; a < 6; ++a) w.bb[a] = bb[a];
+        for (int a = 0; a < 3; ++a) { w.s[a] = s[a]; w.ss[a] = ss[a]; }
+        w.bad = bad;
+        w.cnt = cnt;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {      // one atomic per block and component (same-address atomics serialise)
-        const int a = threadIdx.x;
-        float lo = s_mn[0][a], hi = s_mx[0][a];
-        for (int i = 1; i < kBlock / 64; ++i) { lo = fminf(lo, s_mn[i][a]); hi = fmaxf(hi, s_mx[i][a]); }
-        atomicMin(&red[a], float_order(lo));
-        atomicMax(&red[3 + a], float_order(hi));
+    if (threadIdx.x == 0) {
+        PackRed out = {};            // red was zeroed before the pass; bad / g_begin may have been set directly
+        for (int a = 0; a < 3; ++a) { out.bb[a] = INT32_MAX; out.bb[3 + a] = INT32_MIN; }
+        out.bad = red->bad;
+        out.g_begin = red->g_begin;
+        for (int i = 0; i < kBlock / 64; ++i) {
+            for (int a = 0; a < 3; ++a) {
+                out.bb[a] = min(out.bb[a], sh[i].bb[a]);
+                out.bb[3 + a] = max(out.bb[3 + a], sh[i].bb[3 + a]);
+                out.s[a] += sh[i].s[a];
+                out.ss[a] += sh[i].ss[a];
+            }
+            out.bad |= sh[i].bad;
+            out.cnt += sh[i].cnt;
+        }
+        *red = out;
+        *host_copy = out;
     }
-    if (threadIdx.x == 3) {
-        int b = 0;
-        for (int i = 0; i < kBlock / 64; ++i) b |= s_bad[i];
-        if (b) atomicOr(&red[6], 1);
+}
+
+// xyz (n,3) -> float4 {x,y,z,index}; finite check; bbox and moments (fp64, about the origin: the reference
+// shifts every cloud by its per-axis maximum, pct:56-57, so coordinates are of the order of the extent).
+__global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ xyz, int64_t n,
+                                                 float4* __restrict__ pts4, PackRed* __restrict__ parts) {
+    const float sh[3] = {0.f, 0.f, 0.f};
+    PackAcc acc;
+    acc.init();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+        acc.bad |= !ok;
+        pts4[i] = make_float4(x, y, z, __int_as_float((int)i));
+        if (ok) acc.add(x, y, z, sh);
     }
+    acc.commit(parts + blockIdx.x);
+}
+
+// bbox / finite check of the rows [begin, end) only (the owned range of a sharded handle)
+__global__ __launch_bounds__(kBlock) void k_range_box(const float* __restrict__ xyz, int64_t begin, int64_t end,
+                                                      PackRed* __restrict__ parts) {
+    const float sh[3] = {0.f, 0.f, 0.f};
+    PackAcc acc;
+    acc.init();
+    for (int64_t i = begin + (int64_t)blockIdx.x * kBlock + threadIdx.x; i < end; i += (int64_t)gridDim.x * kBlock) {
+        float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+        acc.bad |= !ok;
+        if (ok) acc.add(x, y, z, sh);
+    }
+    acc.commit(parts + blockIdx.x);
+}
+
+// moments of the packed points inside a box (outlier trimming of the grid box)
+struct Box3 { float lo[3], hi[3]; };
+__device__ __forceinline__ bool in_box(const Box3& b, float x, float y, float z) {
+    return x >= b.lo[0] && x <= b.hi[0] && y >= b.lo[1] && y <= b.hi[1] && z >= b.lo[2] && z <= b.hi[2];
+}
+__global__ __launch_bounds__(kBlock) void k_box_stats(const float4* __restrict__ pts4, int64_t n, Box3 box, Box3 shift,
+                                                      PackRed* __restrict__ parts) {
+    PackAcc acc;
+    acc.init();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const float4 p = pts4[i];
+        if (in_box(box, p.x, p.y, p.z)) acc.add(p.x, p.y, p.z, shift.lo);
+    }
+    acc.commit(parts + blockIdx.x);
+}
+
+// ---- sharded handles: keep only the points near the owned range ------------------------------------------------
+// The candidate set of a handle that owns rows [q_begin, q_end) is the whole cloud, but only the points inside
+// the owned rows' bounding box plus a margin can be neighbours (the sweep verifies that per query, see
+// pct_grid::lim_lo).  Order-preserving compaction in two passes over chunks of kCullChunk rows.
+constexpr int kCullChunk = kBlock * 16;
+
+__global__ __launch_bounds__(kBlock) void k_cull_count(const float* __restrict__ xyz, int64_t n, Box3 box,
+                                                       int* __restrict__ chunk_cnt, PackRed* __restrict__ red) {
+    __shared__ int s_c[kBlock / 64];
+    const int64_t base = (int64_t)blockIdx.x * kCullChunk;
+    int c = 0, bad = 0;
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = base + r * kBlock + threadIdx.x;
+        if (i < n) {
+            const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            bad |= !(isfinite(x) && isfinite(y) && isfinite(z));
+            c += in_box(box, x, y, z);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    bad = __any(bad);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int i = 0; i < kBlock / 64; ++i) t += s_c[i];
+        chunk_cnt[blockIdx.x] = t;
+    }
+    if (bad && (threadIdx.x & 63) == 0) atomicOr(&red->bad, 1);
+}
+
+// single block: exclusive scan of the chunk counts in place, total to cnt[nchunk]
+__global__ __launch_bounds__(1024) void k_scan_chunks(int* __restrict__ cnt, int nchunk, int* __restrict__ host_total) {
+    __shared__ int sh[1024];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < nchunk; base += 1024) {
+        const int i = base + threadIdx.x;
+        const int v = i < nchunk ? cnt[i] : 0;
+        sh[threadIdx.x] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {
+            int a = 0;
+            if ((int)threadIdx.x >= o) a = sh[threadIdx.x - o];
+            __syncthreads();
+            sh[threadIdx.x] += a;
+            __syncthreads();
+        }
+        const int incl = sh[threadIdx.x], c = carry;
+        if (i < nchunk) cnt[i] = c + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = c + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { cnt[nchunk] = carry; *host_total = carry; }
+}
+
+__global__ __launch_bounds__(kBlock) void k_cull_write(const float* __restrict__ xyz, int64_t n, Box3 box,
+                                                       const int* __restrict__ chunk_off, int64_t q_begin,
+                                                       float4* __restrict__ pts4, PackRed* __restrict__ red,
+                                                       PackRed* __restrict__ parts) {
+    __shared__ int s_w[kBlock / 64];
+    const float sh[3] = {0.f, 0.f, 0.f};
+    PackAcc acc;
+    acc.init();
+    const int64_t base = (int64_t)blockIdx.x * kCullChunk;
+    const int w = threadIdx.x >> 6;
+    int running = chunk_off[blockIdx.x];
+    for (int r = 0; r < 16; ++r) {
+        const int64_t i = base + r * kBlock + threadIdx.x;
+        float x = 0.f, y = 0.f, z = 0.f;
+        bool keep = false;
+        if (i < n) {
+            x = xyz[3 * i + 0]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2];
+            keep = in_box(box, x, y, z);
+        }
+        const unsigned long long m = __ballot(keep);
+        if ((threadIdx.x & 63) == 0) s_w[w] = (int)__popcll(m);
+        __syncthreads();
+        int before = 0, total = 0;
+        for (int j = 0; j < kBlock / 64; ++j) {
+            before += j < w ? s_w[j] : 0;
+            total += s_w[j];
+        }
+        if (keep) {
+            const int at = running + before + (int)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+            pts4[at] = make_float4(x, y, z, __int_as_float((int)i));
+            acc.add(x, y, z, sh);
+            if (i == q_begin) red->g_begin = at;
+        }
+        running += total;
+        __syncthreads();
+    }
+    acc.commit(parts + blockIdx.x);
 }
 
 // double4 variant: native float64 coordinates ride along (w = index).
@@ -171,8 +411,10 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ ow
 }
 
 // single block: exclusive scan of the per-tile sums; totals to tmp[nblk]
+struct ScanTotals { unsigned long long sumsq; int4 tot; };
+
 __global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int nblk, const unsigned long long* __restrict__ sq_part,
-                                                      unsigned long long* __restrict__ sumsq) {
+                                                      ScanTotals* __restrict__ host_copy) {
     __shared__ int4 sh[1024];
     __shared__ int4 carry;
     __shared__ unsigned long long shq[16];
@@ -182,7 +424,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int
         for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
         if ((threadIdx.x & 63) == 0) shq[threadIdx.x >> 6] = q;
         __syncthreads();
-        if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += shq[i]; *sumsq = t; }
+        if (threadIdx.x == 0) { unsigned long long t = 0; for (int i = 0; i < 16; ++i) t += shq[i]; host_copy->sumsq = t; }
     }
     if (threadIdx.x == 0) carry = make_int4(0, 0, 0, 0);
     __syncthreads();
@@ -205,7 +447,7 @@ __global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int
         if (threadIdx.x == 1023) carry = add3(c, incl);
         __syncthreads();
     }
-    if (threadIdx.x == 0) tmp[nblk] = carry;
+    if (threadIdx.x == 0) { tmp[nblk] = carry; host_copy->tot = carry; }
 }
 
 __global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ own, const int* __restrict__ oth, int64_t ncell, int items_q,
@@ -245,28 +487,28 @@ __global__ __launch_bounds__(kBlock) void k_scan_apply(const int* __restrict__ o
     if (blockIdx.x == gridDim.x - 1 && threadIdx.x == kBlock - 1) { cell_start[ncell] = s; own_start[ncell] = w; }
 }
 
-// counting-sort scatter, owned points first inside every cell; also records for every public index its
-// neighbour-table row (-1 if not owned) and for every row its sorted position
+// counting-sort scatter, owned points first inside every cell; also records for every owned point its
+// neighbour-table row and for every row its sorted position
 __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ pts4, const int* __restrict__ cell_of,
                                                     const int* __restrict__ cell_start, const int* __restrict__ cell_own,
                                                     const int* __restrict__ own_start, const int* __restrict__ rank_of,
-                                                    int64_t n, float4* __restrict__ sorted4, int* __restrict__ row_of,
-                                                    int* __restrict__ owned_pos,
+                                                    int64_t n, int g_begin, float4* __restrict__ sorted4,
+                                                    int* __restrict__ row_of, int* __restrict__ owned_pos,
                                                     const double4* __restrict__ pts4d, double4* __restrict__ sorted4d) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int c = cell_of[i];
     const int r = rank_of[i];
-    int pos, row = -1;
+    int pos, row;
     if (r >= 0) {
         pos = cell_start[c] + r;
         row = own_start[c] + r;
         owned_pos[row] = pos;
+        row_of[i - g_begin] = row;      // owned points are contiguous in the packed array
     } else {
         pos = cell_start[c] + cell_own[c] + (r & 0x7fffffff);
     }
     sorted4[pos] = pts4[i];
-    row_of[i] = row;
     if (pts4d) sorted4d[pos] = pts4d[i];
 }
 
@@ -285,21 +527,136 @@ int grid_1d(int64_t n, int per_block, int cap) {
 }  // namespace
 
 // ---------------------------------------------------------------------------
-int pct_pack_points(pct_ctx* ctx, float* bbox /*6*/) {
+static PackRed* red_parts(pct_ctx* ctx) { return (PackRed*)((char*)ctx->red.p + 128); }
+
+static int red_reset(pct_ctx* ctx, int n_parts) {
+    PCT_TRY(pct_reserve(ctx, &ctx->red, 128 + (size_t)n_parts * sizeof(PackRed)));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 128, ctx->stream));
+    return PCT_OK;
+}
+
+// folds the n_parts block records of the pass just launched and reads the result back
+static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
+    hipLaunchKernelGGL(k_pack_final, dim3(1), dim3(kBlock), 0, ctx->stream, (const PackRed*)red_parts(ctx), n_parts,
+                       (PackRed*)ctx->red.p, (PackRed*)ctx->pin);
+    PCT_HIP(ctx, hipGetLastError());
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out, ctx->pin, sizeof(*out));
+    for (int a = 0; a < 6; ++a) bbox[a] = order_float(out->bb[a]);
+    return PCT_OK;
+}
+
+// every point, public order
+static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red) {
     const int64_t n = ctx->n;
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));
-    PCT_TRY(pct_reserve(ctx, &ctx->red, 64));
-    int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->red.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_pack, dim3(grid_1d(n, kBlock * 4, 512)), dim3(kBlock), 0, ctx->stream,
-                       (const float*)ctx->xyz.p, n, (float4*)ctx->pts4.p, (int*)ctx->red.p);
+    const int nb = grid_1d(n, kBlock * 4, 512);
+    PCT_TRY(red_reset(ctx, nb));
+    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       (const float*)ctx->xyz.p, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
-    int out[8];
-    PCT_HIP(ctx, hipMemcpyAsync(out, ctx->red.p, sizeof(out), hipMemcpyDeviceToHost, ctx->stream));
-    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (out[6]) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
-    for (int a = 0; a < 6; ++a) bbox[a] = order_float(out[a]);
+    PCT_TRY(red_read(ctx, nb, red, bbox));
+    if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
     ctx->pts4_valid = true;
+    ctx->n_grid = n;
+    ctx->g_begin = ctx->q_begin;
+    ctx->culled = false;
+    return PCT_OK;
+}
+
+int pct_pack_points(pct_ctx* ctx, float* bbox /*6*/) {
+    PackRed red;
+    return pack_all(ctx, bbox, &red);
+}
+
+// Sharded handle: pack only the points inside the owned rows' bounding box grown by `margin_cells` first-guess
+// cell edges.  *kept_box receives the box that was applied (its faces become pct_grid::lim_*).
+static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* red, Box3* kept_box) {
+    const int64_t n = ctx->n, n_owned = ctx->q_end - ctx->q_begin;
+    const int nb = grid_1d(n_owned, kBlock * 4, 512);
+    PCT_TRY(red_reset(ctx, nb));
+    hipLaunchKernelGGL(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream,
+                       (const float*)ctx->xyz.p, ctx->q_begin, ctx->q_end, red_parts(ctx));
+    PCT_HIP(ctx, hipGetLastError());
+    float ob[6];
+    PCT_TRY(red_read(ctx, nb, red, ob));
+    if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    // margin: 4 cell edges of the cell size the owned points alone would get (an over-estimate of the final
+    // edge whenever other handles' points share the region); the sweep checks the assumption per query
+    const double ex = (double)ob[3] - ob[0], ey = (double)ob[4] - ob[1], ez = (double)ob[5] - ob[2];
+    const double emax = fmax(ex, fmax(ey, ez));
+    double area = 1.2 * (ex * ey + ey * ez + ex * ez);
+    if (!(area > 0)) area = emax * emax;
+    double a0 = sqrt(target * area / (double)n_owned);
+    if (!(a0 > 0) || !isfinite(a0)) a0 = emax;
+    const float margin = (float)(4.0 * a0);
+    Box3 box;
+    for (int a = 0; a < 3; ++a) { box.lo[a] = ob[a] - margin; box.hi[a] = ob[3 + a] + margin; }
+    *kept_box = box;
+
+    const int nchunk = (int)((n + kCullChunk - 1) / kCullChunk);
+    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nchunk + 1) * sizeof(int)));
+    PCT_TRY(red_reset(ctx, nchunk));
+    hipLaunchKernelGGL(k_cull_count, dim3(nchunk), dim3(kBlock), 0, ctx->stream, (const float*)ctx->xyz.p, n, box,
+                       (int*)ctx->scan_tmp.p, (PackRed*)ctx->red.p);
+    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, ctx->stream, (int*)ctx->scan_tmp.p, nchunk, (int*)(ctx->pin + 160));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int kept = *(const int*)(ctx->pin + 160);
+    PCT_HIP(ctx, hipGetLastError());
+    PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)kept * sizeof(float4)));
+    hipLaunchKernelGGL(k_cull_write, dim3(nchunk), dim3(kBlock), 0, ctx->stream, (const float*)ctx->xyz.p, n, box,
+                       (const int*)ctx->scan_tmp.p, ctx->q_begin, (float4*)ctx->pts4.p, (PackRed*)ctx->red.p, red_parts(ctx));
+    PCT_HIP(ctx, hipGetLastError());
+    PCT_TRY(red_read(ctx, nchunk, red, bbox));
+    if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    if ((int64_t)red->cnt != kept || kept < n_owned)
+        return pct_fail(ctx, PCT_ERR_INVALID, "cull pass kept %lld / counted %d points", (long long)red->cnt, kept);
+    ctx->pts4_valid = false;                 // pts4 is not the full public-order pack
+    ctx->n_grid = kept;
+    ctx->g_begin = red->g_begin;
+    ctx->culled = kept < n;
+    return PCT_OK;
+}
+
+// Outlier-trimmed grid box.  A few far outliers would stretch the bounding box until the whole cloud falls into
+// a handful of cells.  Cell coordinates are clamped, and a clamped point is never nearer than its boundary cell
+// suggests, so the grid may cover any sub-box: take mean +- 6 sigma per axis (re-estimated inside the box until
+// it settles) and let the points outside share the boundary cells.  Clouds without outliers keep their bbox:
+// a uniform or surface-like distribution spans about +-1.7 sigma.
+static int trim_box(pct_ctx* ctx, const PackRed& first, float* bbox) {
+    PackRed r = first;
+    float sh[3] = {0.f, 0.f, 0.f};           // the moments in `first` are about the origin
+    for (int pass = 0; pass < 5; ++pass) {
+        if (r.cnt < 2) break;
+        bool shrunk = false;
+        float nb[6];
+        for (int a = 0; a < 3; ++a) {
+            const double mean = r.s[a] / (double)r.cnt, var = fmax(r.ss[a] / (double)r.cnt - mean * mean, 0.0);
+            const double sd = sqrt(var), c = (double)sh[a] + mean;
+            const double lo = fmax((double)bbox[a], c - 6.0 * sd), hi = fmin((double)bbox[3 + a], c + 6.0 * sd);
+            const double cut = fmax(lo - bbox[a], 0.0) + fmax((double)bbox[3 + a] - hi, 0.0);
+            nb[a] = bbox[a];
+            nb[3 + a] = bbox[3 + a];
+            if (cut > 0.25 * (hi - lo) && hi > lo) {           // worth it only if a good part of the extent goes
+                nb[a] = (float)lo;
+                nb[3 + a] = (float)hi;
+                shrunk = true;
+            }
+        }
+        if (!shrunk) break;
+        for (int a = 0; a < 6; ++a) bbox[a] = nb[a];
+        Box3 box, shift;
+        for (int a = 0; a < 3; ++a) { box.lo[a] = bbox[a]; box.hi[a] = bbox[3 + a]; shift.lo[a] = shift.hi[a] = 0.5f * (bbox[a] + bbox[3 + a]); }
+        for (int a = 0; a < 3; ++a) sh[a] = shift.lo[a];
+        const int nblk = grid_1d(ctx->n_grid, kBlock * 4, 512);
+        PCT_TRY(red_reset(ctx, nblk));
+        hipLaunchKernelGGL(k_box_stats, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+                           (const float4*)ctx->pts4.p, ctx->n_grid, box, shift, red_parts(ctx));
+        PCT_HIP(ctx, hipGetLastError());
+        float inner[6];
+        PCT_TRY(red_read(ctx, nblk, &r, inner));
+        ++ctx->tm.grid_iters;     // counted with the cell-size passes
+    }
     return PCT_OK;
 }
 
@@ -330,15 +687,26 @@ static void set_dims(pct_grid* g, const float* bbox, double a) {
 // points for nearly every query of a surface-like cloud; the sweep kernel
 // widens ring by ring for the rest.
 int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
-    const int64_t n = ctx->n;
-    float bbox[6];
-    PCT_TRY(pct_pack_points(ctx, bbox));
-
     // measured optima on surface clouds (tools/tune_factor.py): larger cells cost candidates, smaller ones cost
     // trips to the exact sweep; the LDS staging capacity caps the large side
     const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 32 ? 0.65 : k + 1 <= 64 ? 0.55 : 0.45);
     const double target = factor * (k + 1);
     const int64_t cell_cap = (int64_t)1 << 27;
+    const int64_t n_owned = ctx->q_end - ctx->q_begin;
+    const bool sharded = ctx->q_begin > 0 || ctx->q_end < ctx->n;        // some points are candidates only
+
+    float bbox[6];
+    PackRed red;
+    Box3 kept_box = {};
+    const bool try_cull = sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !getenv("PCT_NO_CULL");
+    ctx->tm.grid_iters = 0;
+    if (try_cull)
+        PCT_TRY(pack_near_owned(ctx, target, bbox, &red, &kept_box));
+    else
+        PCT_TRY(pack_all(ctx, bbox, &red));
+    PCT_TRY(trim_box(ctx, red, bbox));
+    const int64_t n = ctx->n_grid;                                        // points the grid holds
+    const int g_begin = (int)ctx->g_begin, g_end = (int)(ctx->g_begin + n_owned);
 
     double ex = (double)bbox[3] - bbox[0], ey = (double)bbox[4] - bbox[1], ez = (double)bbox[5] - bbox[2];
     double emax = fmax(ex, fmax(ey, ez));
@@ -348,25 +716,31 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     if (!(area > 0)) area = emax * emax;
     double a = sqrt(target * area / (double)n);
     if (!(a > 0) || !isfinite(a)) a = emax;
+    // Warm start: a handle that sees a stream of similar clouds (same scanner, same shard of the same job) reuses
+    // the edge the last build converged to, rescaled by the first-guess ratio, and so normally needs one pass.
+    const double first_guess_raw = a;
+    if (ctx->hint_edge > 0 && ctx->hint_guess > 0) {
+        const double r = first_guess_raw / ctx->hint_guess * sqrt(ctx->hint_target / target);   // guess ~ sqrt(target)
+        if (r > 0.5 && r < 2.0) a = ctx->hint_edge * r * sqrt(target / ctx->hint_target);
+    }
     a = fmin(a, emax * 1.0001 + 1e-30);
 
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
-    const bool sharded = ctx->q_begin > 0 || ctx->q_end < n;             // some points are candidates only
     int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
     if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
-    const int64_t n_owned = ctx->q_end - ctx->q_begin;
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
-    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)n * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)(n_owned + 1) * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, (size_t)n_owned * sizeof(int)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
     int nblk = 0;
     pct_grid g = {};
     double a_prev = 0, m_prev = 0;
     int iters = 0;
-    const int max_iter = 6;
+    const int max_iter = 8;
     int4 tot = make_int4(0, 0, 0, 0);
+    double m_last = 0, d_last = 2.0;
     // Every pass runs the whole build (histogram, scan, scatter) and only then reads back the occupancy statistic
     // together with the scan totals: the first cell size is accepted in the common case, which then costs ONE host
     // synchronisation instead of two; a rejected size costs a speculative scatter.
@@ -383,9 +757,8 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
             PCT_TRY(pct_reserve(ctx, &ctx->cell_oth, (size_t)g.ncell * sizeof(int)));
             PCT_HIP(ctx, hipMemsetAsync(ctx->cell_oth.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
         }
-        PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 16, ctx->stream));
         hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, n, g, (int)ctx->q_begin, (int)ctx->q_end, (int*)ctx->cell_of.p,
+                           (const float4*)ctx->pts4.p, n, g, g_begin, g_end, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
@@ -397,26 +770,26 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (int4*)ctx->scan_tmp.p, sq_part);
         hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
-                           (const unsigned long long*)sq_part, (unsigned long long*)ctx->red.p);
+                           (const unsigned long long*)sq_part, (ScanTotals*)(ctx->pin + 128));
         hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
         hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                            (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
                            (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
-                           (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
+                           g_begin, (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
                            ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
                            ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
         PCT_HIP(ctx, hipGetLastError());
-        unsigned long long s2 = 0;
-        PCT_HIP(ctx, hipMemcpyAsync(&s2, ctx->red.p, 8, hipMemcpyDeviceToHost, ctx->stream));
-        PCT_HIP(ctx, hipMemcpyAsync(&tot, (int4*)ctx->scan_tmp.p + nblk, sizeof(int4), hipMemcpyDeviceToHost, ctx->stream));
         PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        const unsigned long long s2 = ((const ScanTotals*)(ctx->pin + 128))->sumsq;
+        tot = ((const ScanTotals*)(ctx->pin + 128))->tot;
         ++iters;
         double m = (double)s2 / (double)n;
+        m_last = m;
         bool eps_bound = eps > 0 && a >= eps;            // cannot grow past eps
         bool capped = g.ncell * 2 > cell_cap && m < target;
-        if ((m >= 0.8 * target && m <= 1.3 * target) || it == max_iter - 1 || (eps_bound && m < target) ||
+        if ((m >= 0.88 * target && m <= 1.12 * target) || it == max_iter - 1 || (eps_bound && m < target) ||
             capped || (a >= emax && m < target))
             break;
         double d = 2.0;
@@ -427,16 +800,37 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         }
         a_prev = a;
         m_prev = m;
+        d_last = d;
         double f = pow(target / m, 1.0 / d);
-        f = fmin(fmax(f, 0.25), 4.0);
+        f = fmin(fmax(f, 1.0 / 16.0), 16.0);
         a = fmin(a * f, emax * 1.0001 + 1e-30);
     }
+    // faces of the culling box become limits of what the grid can vouch for (cell units from the origin)
+    for (int ax = 0; ax < 3; ++ax) {
+        const double o = ax == 0 ? g.ox : ax == 1 ? g.oy : g.oz;
+        g.lim_lo[ax] = ctx->culled ? ((double)kept_box.lo[ax] - o) * g.inv_cell : -INFINITY;
+        g.lim_hi[ax] = ctx->culled ? ((double)kept_box.hi[ax] - o) * g.inv_cell : INFINITY;
+    }
     ctx->grid = g;
-    ctx->tm.grid_iters = iters;
+    ctx->tm.grid_iters += iters;
     ctx->tm.cells = g.ncell;
     ctx->tm.cell_size = g.cell;
+    ctx->tm.grid_points = n;
+    ctx->tm.occupancy = m_last;
+    if (m_last > 0) {        // what the heuristic first guess should have been for this cloud
+        ctx->hint_edge = g.cell * pow(target / m_last, 1.0 / d_last);
+        ctx->hint_guess = first_guess_raw;
+        ctx->hint_target = target;
+    }
     if (tot.x != n || tot.z != n_owned)
         return pct_fail(ctx, PCT_ERR_INVALID, "cell scan totals %d/%d != %lld/%lld", tot.x, tot.z, (long long)n, (long long)n_owned);
+    // A uniform cell list cannot resolve every cloud (tight clusters very far apart exhaust the cell budget):
+    // refuse when the sweep would degenerate into an all-pairs scan of hours rather than run it.
+    if (m_last > 64.0 * target && m_last * 27.0 * (double)n_owned > 1e12)
+        return pct_fail(ctx, PCT_ERR_INVALID,
+                        "the cell list cannot resolve this cloud: a point shares its cell with %.0f others on average at the "
+                        "smallest usable cell edge %.3g (%lld cells); thin it out or split it into compact pieces",
+                        m_last, g.cell, (long long)g.ncell);
     ctx->n_items = tot.y;
     ctx->n_occ = tot.y;
     ctx->tm.occupied_cells = tot.y;

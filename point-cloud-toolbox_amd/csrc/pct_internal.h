@@ -21,6 +21,9 @@ struct pct_grid {
     double inv_cell;
     int32_t nx, ny, nz;
     int64_t ncell;
+    // Faces beyond which points of the cloud were left out of this grid (a sharded handle keeps only the points
+    // near its owned range), in cell units from the origin; -inf / +inf = nothing was left out on that side.
+    double lim_lo[3], lim_hi[3];
 };
 
 struct pct_buf {
@@ -36,13 +39,21 @@ struct pct_ctx {
 
     int64_t n = 0;                 // cloud size (candidates)
     int64_t q_begin = 0, q_end = 0;
+    // Points the grid holds: all n, or -- sharded handles -- the points inside the owned range's bounding box plus
+    // a margin, compacted in public order (pts4.w keeps the public index).  g_begin = position of the first owned
+    // point in that compacted array (== q_begin when nothing was left out).
+    int64_t n_grid = 0, g_begin = 0;
+    bool culled = false;           // the grid holds fewer than n points
+    bool no_cull = false;          // set after a sweep met a query the kept points cannot answer
+    int32_t retries = 0;
+    double hint_edge = 0, hint_guess = 0, hint_target = 0;   // warm start of the cell-size search (pct_build_grid)
     bool has_f64 = false;
     double occupancy_factor = 0.0; // 0 = default
     bool collect_stats = false;    // sweep statistics (costly same-address atomics)
 
     // coordinates
     pct_buf xyz;        // float  (n,3) public order
-    pct_buf pts4;       // float4 (n) public order, w = own index bits
+    pct_buf pts4;       // float4 (n_grid) public order, w = public index bits
     pct_buf pts4d;      // double4 (n) public order (only when has_f64), w = index
     // grid
     pct_grid grid = {};
@@ -59,9 +70,13 @@ struct pct_ctx {
     int32_t items_q = 12;
     pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
     pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
-    pct_buf row_of;     // int32 (n) neighbour-table row of every public index (-1 = not owned)
+    pct_buf row_of;     // int32 (owned) neighbour-table row of public index q_begin + i
     pct_buf owned_pos;  // int32 (owned) sorted position of every table row
     pct_buf red;        // small reduction scratch
+    // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
+    // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
+    // [192,256) sweep counters
+    unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;
     bool pts4_valid = false;

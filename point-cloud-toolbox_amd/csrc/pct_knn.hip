@@ -55,7 +55,7 @@ struct KnnArgs {
     float* nbr_dist;
     int* nbr_cnt;             // nullable
     int stats;                // collect the counters below (off by default)
-    unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries
+    unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries [5] queries beyond the culling limits (always counted)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
@@ -357,6 +357,17 @@ __device__ __forceinline__ double guaranteed_r2(const pct_grid& g, int cx, int c
     return rr * rr;
 }
 
+// Squared distance from the query to the nearest face beyond which points were left out of the grid
+// (pct_grid::lim_*): nothing the kept points say is proven past it.  +inf for a grid that holds the whole cloud.
+__device__ __forceinline__ double limit_r2(const pct_grid& g, int cx, int cy, int cz, double gx, double gy, double gz) {
+    const double px = cx + gx, py = cy + gy, pz = cz + gz;
+    double t = fmin(px - g.lim_lo[0], g.lim_hi[0] - px);
+    t = fmin(t, fmin(py - g.lim_lo[1], g.lim_hi[1] - py));
+    t = fmin(t, fmin(pz - g.lim_lo[2], g.lim_hi[2] - pz));
+    const double rr = fmax(t, 0.0) * g.cell * (1.0 - 1e-6);
+    return rr * rr;
+}
+
 __device__ __forceinline__ int cell_coord_d(double x, double o, double inv, int n) {
     int c = (int)floor((x - o) * inv);
     return min(max(c, 0), n - 1);
@@ -425,7 +436,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             }
             if (sw.npend > 0 || sw.empty) sw.flush();
             if (have) continue;
-            if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, it.ring)) break;
+            if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, it.ring)) {
+                // final among the kept points; a handle that left points out must also be inside its limits
+                if (lane == 0 && fmin(sw.tau_d, sw.eps2) > limit_r2(g, cx, cy, cz, gx, gy, gz)) atomicAdd(&a.counters[5], 1ull);
+                break;
+            }
             it.start(it.ring + 1, false);
             have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
             if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
@@ -612,7 +627,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         const double gx = (lqx - g.ox) * g.inv_cell - cx;
         const double gy = (lqy - g.oy) * g.inv_cell - cy;
         const double gz = (lqz - g.oz) * g.inv_cell - cz;
-        my_gkey = (unsigned)(guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1) * scale);     // saturates: +inf -> 0xFFFFFFFF
+        // 0xFFFFFFFF only when nothing bounds the answer (the cube covers the grid and no points were left out):
+        // that alone vouches for "fewer than k+1 points exist".  A query clamped into a boundary cell from far
+        // outside the grid box can have a finite guarantee beyond the key range: keep it below the sentinel.
+        const double g2 = fmin(guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1), limit_r2(g, cx, cy, cz, gx, gy, gz));
+        my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     // ceil(eps^2 * scale): the whole eps ball must be inside the guaranteed radius too
     const unsigned eps_key = eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
@@ -722,8 +741,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up; all in key units)
         {
             const unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
-            const unsigned need = min((tau >> SLOT_BITS) + 1u, eps_key);     // padding: 2^KEY_BITS, never vouched for
+            const unsigned tkey = tau >> SLOT_BITS;
+            const unsigned need = min(tau == kPadElem ? 0xFFFFFFFFu : tkey + 1u, eps_key);
             amb |= need > gkey;
+            // a saturated key (a point clamped into a boundary cell from outside the grid box) says nothing
+            // about the true distance
+            amb |= tau != kPadElem && tkey >= key_max;
         }
         // ---- neighbours with equal keys inside the first k+2 entries: order not proven
         {
@@ -856,7 +879,7 @@ __global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ 
                                                      float* __restrict__ dist_out, int* __restrict__ cnt_out) {
     const int64_t r = blockIdx.x;
     const int64_t pub = rows[r];
-    const int64_t row = row_of ? row_of[pub] : pub - q_begin;
+    const int64_t row = row_of ? row_of[pub - q_begin] : pub - q_begin;
     for (int j = threadIdx.x; j < k; j += 128) {
         const int pos = nbr_pos[row * pitch + j];
         if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);

@@ -63,6 +63,21 @@ def torus_random(n, seed=1234, R=TORUS_R, r=TORUS_r, dtype=np.float32, lo=0, hi=
     return p, K, H
 
 
+def torus_scan_order(n, parts, part, seed=1234, R=TORUS_R, r=TORUS_r, dtype=np.float32):
+    """Rows of part ``part`` of an n-point random torus whose index order follows the major angle.
+
+    The reference's generator walks the surface theta-major (utils.py:888-891) and scanners emit points along
+    their sweep, so contiguous index ranges are spatially compact.  This is the random-parameter equivalent:
+    part p (rows [n*p//parts, n*(p+1)//parts)) holds theta ~ U[2 pi p/parts, 2 pi (p+1)/parts), phi ~ U[0, 2 pi),
+    in random order inside the part.  ``parts == 1`` is not ``torus_random`` (different stream).
+    """
+    lo, hi = (n * part) // parts, (n * (part + 1)) // parts
+    rng = np.random.default_rng([seed, parts, part])
+    u = rng.uniform(0.0, 1.0, size=(hi - lo, 2))
+    ang = np.stack([2.0 * np.pi * (part + u[:, 0]) / parts, 2.0 * np.pi * u[:, 1]], 1)
+    return torus_from_angles(ang, R, r, dtype)
+
+
 def torus_grid(n_side, R=TORUS_R, r=TORUS_r, dtype=np.float32):
     """Reference-style theta x phi lattice (utils.py:888-896); many k-NN ties."""
     t = np.linspace(0.0, 2.0 * np.pi, n_side)

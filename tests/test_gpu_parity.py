@@ -289,6 +289,90 @@ def test_query_range_shards_are_bit_identical(gpu):
         assert np.array_equal(np.concatenate([p[j] for p in parts]), ref)
 
 
+def test_scan_ordered_shards_keep_only_nearby_points(gpu):
+    """A handle that owns a spatially coherent index range (scan order) packs only the points near it;
+    every value stays bit-identical to the unsharded run."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(200_000, seed=16)
+    theta = np.arctan2(pts[:, 1], pts[:, 0])
+    pts = np.ascontiguousarray(pts[np.argsort(theta, kind="stable")])
+    n = len(pts)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.curvature(50)
+    i0, d0, _ = h.get_neighbors(0, n)
+    c0, K0, H0, _ = h.get_fit(0, n)
+    assert h.timings()["grid_points"] == n
+    world = 4
+    for r in range(world):
+        lo, hi = n * r // world, n * (r + 1) // world
+        h.set_query_range(lo, hi)
+        h.curvature(50)
+        t = h.timings()
+        assert hi - lo < t["grid_points"] < 0.6 * n, t            # own quarter + halo, not the cloud
+        assert t["limit_retries"] == 0
+        i, d, _ = h.get_neighbors(lo, hi)
+        c, K, H, _ = h.get_fit(lo, hi)
+        assert np.array_equal(i, i0[lo:hi]) and np.array_equal(d, d0[lo:hi])
+        assert np.array_equal(c, c0[lo:hi]) and np.array_equal(K, K0[lo:hi]) and np.array_equal(H, H0[lo:hi])
+        rows = np.array([lo, (lo + hi) // 2, hi - 1], dtype=np.int64)
+        ir, dr, _ = h.get_neighbor_rows(rows)
+        assert np.array_equal(ir, i0[rows]) and np.array_equal(dr, d0[rows])
+    h.close()
+
+
+def test_shard_whose_neighbours_lie_past_the_kept_part_is_redone(gpu):
+    """Owned rows = a tight cluster smaller than k+1: the neighbours are far-away points the first pack left
+    out; the sweep notices and repeats with the whole cloud."""
+    capi = gpu["capi"]
+    rng = np.random.default_rng(23)
+    cluster = rng.normal(scale=1e-3, size=(20, 3))
+    rest = rng.uniform(2.0, 3.0, size=(30_000, 3))
+    pts = np.vstack([cluster, rest]).astype(np.float32)
+    idx, d = oracle.knn(pts, 30)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.set_query_range(0, 20)
+    h.knn(30, algo=capi.KNN_GRID)
+    t = h.timings()
+    assert t["limit_retries"] == 1 and t["grid_points"] == len(pts)
+    i, dd, _ = h.get_neighbors(0, 20)
+    assert np.array_equal(i, idx[:20]) and np.array_equal(dd, d[:20])
+    h.close()
+
+
+def test_far_outliers_do_not_coarsen_the_cell_list(gpu):
+    """A few points far from the cloud stretch the bounding box; the grid box is trimmed to mean +- 6 sigma and
+    the outliers share the boundary cells.  Results stay exact, the cell edge stays that of the clean cloud."""
+    pts = gpu["shapes"].torus_random(60_000, seed=4)
+    pc0, _, _ = run_cloud(gpu, pts, 30, algorithm="grid")
+    cell0 = pc0.last_timings["cell_size"]
+    far = np.array([[90.0, -40.0, 3.0], [-150.0, 2.0, 80.0], [5.0, 70.0, -2.0]], dtype=np.float32)
+    both = np.vstack([pts, far]).astype(np.float32)
+    pc, K, H = run_cloud(gpu, both, 30, algorithm="grid")
+    t = pc.last_timings
+    assert t["cell_size"] < 1.5 * cell0, (t["cell_size"], cell0)
+    ref = oracle.pipeline_batched(np.asarray(pc.points), 30)
+    assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
+    clean = np.arange(len(both)) < len(pts)          # the outliers' own quadrics are ill-conditioned by construction
+    assert_curvature(K, H, ref["K"], ref["H"], mask=clean)
+
+
+def test_unresolvable_cloud_is_refused_not_run(gpu):
+    """Two tight clusters very far apart cannot be separated by 2^27 cells: the all-pairs sweep that would
+    follow takes hours, so the call fails with a message instead."""
+    capi = gpu["capi"]
+    rng = np.random.default_rng(3)
+    a = rng.normal(scale=1e-4, size=(300_000, 3))
+    b = rng.normal(scale=1e-4, size=(300_000, 3)) + 1000.0
+    pts = np.vstack([a, b]).astype(np.float32)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    with pytest.raises(ValueError, match="cannot resolve"):
+        h.knn(30, algo=capi.KNN_GRID)
+    h.close()
+
+
 def test_fused_entry_matches_stepwise(gpu):
     pts = gpu["shapes"].egg_carton_random(25_000, seed=9)
     a, Ka, Ha = run_cloud(gpu, pts, 50)

@@ -7,9 +7,14 @@ ge.build()
 from point_cloud_toolbox_amd import _capi, shapes
 from point_cloud_toolbox_amd.dist import shard_range
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+import numpy as np
+order = sys.argv[2] if len(sys.argv) > 2 else "scan"
 for G in (1, 2, 4, 8):
     n = per * G
-    pts = shapes.torus_random(n, seed=1234)
+    if order == "scan":
+        pts = np.concatenate([shapes.torus_scan_order(n, G, r, seed=1234) for r in range(G)])
+    else:
+        pts = shapes.torus_random(n, seed=1234)
     h = _capi.Handle(0)
     h.set_points(pts)
     lo, hi = shard_range(n, G - 1, G)
@@ -20,6 +25,7 @@ for G in (1, 2, 4, 8):
         t = h.timings()
         if best is None or t["total_ms"] < best["total_ms"]:
             best = t
+    print(f"[{order}] grid_points {best['grid_points']} retries {best['limit_retries']} ", end="")
     print(f"G={G} N={n}: grid {best['grid_ms']:.3f} knn {best['knn_ms']:.3f} fit {best['fit_ms']:.3f} total {best['total_ms']:.3f} ms "
           f"-> {G * per / best['total_ms'] / 1e3:.1f} Mpts/s aggregate if all ranks alike (no all-gather)", flush=True)
     h.close()

@@ -21,4 +21,4 @@ for f in [float(x) for x in (sys.argv[3:] or "0.2 0.25 0.3 0.35 0.4 0.45 0.55".s
         if best is None or t["knn_ms"] < best["knn_ms"]:
             best = t
     print(f"factor {f:.2f}: knn {best['knn_ms']:.3f} ms grid {best['grid_ms']:.3f} fit {best['fit_ms']:.3f} total {best['total_ms']:.3f} | cell {best['cell_size']:.4f} occ {best['occupied_cells']} "
-          f"fallback {best['ring_fallbacks']} ovf {best['lds_overflows']} flush/q {best['flushes']/n:.2f} steps/q {best['candidate_steps']/n:.2f} iters {best['grid_iters']}")
+          f"fallback {best['ring_fallbacks']} ovf {best['lds_overflows']} flush/q {best['flushes']/n:.2f} steps/q {best['candidate_steps']/n:.2f} iters {best['grid_iters']} m {best['occupancy']:.1f} redo {best['redone_queries']}")
