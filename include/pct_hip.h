@@ -81,6 +81,11 @@ int pct_set_points_f64(pct_ctx* ctx, const double* xyz, int64_t n);
 /* Same, from a device pointer on this handle's device (multi-GPU: the buffer
  * an RCCL all-gather has just filled). */
 int pct_set_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n);
+/* Same without the copy: the handle reads the caller's buffer in place.  The
+ * buffer must stay allocated and unchanged until the next pct_set_points_* /
+ * pct_use_points_* call on this handle or pct_destroy, and whatever filled it
+ * must have completed (the handle's stream does not wait for other streams). */
+int pct_use_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n);
 /* Queries owned by this handle: global index range [begin, end).  Default all. */
 int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end);
 /* Cell-occupancy target of the grid search as a multiple of (k+1); <= 0 keeps

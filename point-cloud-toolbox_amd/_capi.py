@@ -59,6 +59,7 @@ SIGNATURES = {
     "pct_set_points_f32": (C.c_int, [_p, _f32p, C.c_int64]),
     "pct_set_points_f64": (C.c_int, [_p, _f64p, C.c_int64]),
     "pct_set_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
+    "pct_use_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
     "pct_set_query_range": (C.c_int, [_p, C.c_int64, C.c_int64]),
     "pct_set_grid_param": (C.c_int, [_p, C.c_double]),
     "pct_set_stats": (C.c_int, [_p, C.c_int32]),
@@ -208,6 +209,11 @@ class Handle:
 
     def set_points_device(self, dev_ptr, n):
         self._check(self._lib.pct_set_points_device_f32(self._h, _p(int(dev_ptr)), int(n)))
+        self.n = int(n)
+
+    def use_points_device(self, dev_ptr, n):
+        """Zero-copy variant: the caller keeps the buffer alive and unchanged while the handle uses it."""
+        self._check(self._lib.pct_use_points_device_f32(self._h, _p(int(dev_ptr)), int(n)))
         self.n = int(n)
 
     def set_query_range(self, begin, end):

@@ -130,6 +130,7 @@ int pct_set_points_f32(pct_ctx* ctx, const float* xyz, int64_t n) {
     PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
     PCT_HIP(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
     PCT_HIP(ctx, hipMemcpyAsync(ctx->xyz.p, xyz, (size_t)n * 3 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    ctx->xyz_view = (const float*)ctx->xyz.p;
     PCT_HIP(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.upload_ms = ev_ms(ctx, 0, 1);
@@ -158,6 +159,20 @@ int pct_set_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n) {
     PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
     PCT_HIP(ctx, hipMemcpyAsync(ctx->xyz.p, dev_xyz, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->xyz_view = (const float*)ctx->xyz.p;
+    return PCT_OK;
+}
+
+int pct_use_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n) {
+    PCT_TRY(begin_call(ctx));
+    if (!dev_xyz) return pct_fail(ctx, PCT_ERR_INVALID, "null coordinates");
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, dev_xyz) != hipSuccess || attr.type != hipMemoryTypeDevice || attr.device != ctx->device) {
+        (void)hipGetLastError();
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_use_points_device_f32: not a device pointer of device %d", ctx->device);
+    }
+    PCT_TRY(new_cloud(ctx, n));
+    ctx->xyz_view = (const float*)dev_xyz;
     return PCT_OK;
 }
 

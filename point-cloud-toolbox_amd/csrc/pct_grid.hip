@@ -553,7 +553,7 @@ static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red) {
     const int nb = grid_1d(n, kBlock * 4, 512);
     PCT_TRY(red_reset(ctx, nb));
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       (const float*)ctx->xyz.p, n, (float4*)ctx->pts4.p, red_parts(ctx));
+                       ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     PCT_TRY(red_read(ctx, nb, red, bbox));
     if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
@@ -576,7 +576,7 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     const int nb = grid_1d(n_owned, kBlock * 4, 512);
     PCT_TRY(red_reset(ctx, nb));
     hipLaunchKernelGGL(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       (const float*)ctx->xyz.p, ctx->q_begin, ctx->q_end, red_parts(ctx));
+                       ctx->xyz_view, ctx->q_begin, ctx->q_end, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     float ob[6];
     PCT_TRY(red_read(ctx, nb, red, ob));
@@ -597,14 +597,14 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     const int nchunk = (int)((n + kCullChunk - 1) / kCullChunk);
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nchunk + 1) * sizeof(int)));
     PCT_TRY(red_reset(ctx, nchunk));
-    hipLaunchKernelGGL(k_cull_count, dim3(nchunk), dim3(kBlock), 0, ctx->stream, (const float*)ctx->xyz.p, n, box,
+    hipLaunchKernelGGL(k_cull_count, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box,
                        (int*)ctx->scan_tmp.p, (PackRed*)ctx->red.p);
     hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, ctx->stream, (int*)ctx->scan_tmp.p, nchunk, (int*)(ctx->pin + 160));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int kept = *(const int*)(ctx->pin + 160);
     PCT_HIP(ctx, hipGetLastError());
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)kept * sizeof(float4)));
-    hipLaunchKernelGGL(k_cull_write, dim3(nchunk), dim3(kBlock), 0, ctx->stream, (const float*)ctx->xyz.p, n, box,
+    hipLaunchKernelGGL(k_cull_write, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box,
                        (const int*)ctx->scan_tmp.p, ctx->q_begin, (float4*)ctx->pts4.p, (PackRed*)ctx->red.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     PCT_TRY(red_read(ctx, nchunk, red, bbox));
@@ -666,6 +666,7 @@ int pct_pack_points_f64(pct_ctx* ctx, const double* d_xyz64) {
     PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
     hipLaunchKernelGGL(k_pack_f64, dim3(grid_1d(n, kBlock, 2048)), dim3(kBlock), 0, ctx->stream,
                        d_xyz64, n, (double4*)ctx->pts4d.p, (float*)ctx->xyz.p);
+    ctx->xyz_view = (const float*)ctx->xyz.p;
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

@@ -52,7 +52,8 @@ struct pct_ctx {
     bool collect_stats = false;    // sweep statistics (costly same-address atomics)
 
     // coordinates
-    pct_buf xyz;        // float  (n,3) public order
+    pct_buf xyz;        // float  (n,3) public order (owned copy)
+    const float* xyz_view = nullptr;   // the coordinates in use: xyz.p, or a caller's buffer (pct_use_points_device_f32)
     pct_buf pts4;       // float4 (n_grid) public order, w = public index bits
     pct_buf pts4d;      // double4 (n) public order (only when has_f64), w = index
     // grid

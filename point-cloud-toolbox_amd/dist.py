@@ -81,13 +81,28 @@ class ShardedCurvature:
         return self.download()
 
     def run_device(self, full):
-        """Hand the gathered device buffer to the HIP path (no host copy)."""
+        """Hand the gathered device buffer to the HIP path in place (no copy): ``full`` must stay unchanged
+        until the next call."""
         import torch
         torch.cuda.current_stream(full.device).synchronize()     # the collective ran on torch's stream
         h = self.handle
-        h.set_points_device(full.data_ptr(), self.n_total)
+        h.use_points_device(full.data_ptr(), self.n_total)
         h.set_query_range(self.lo, self.hi)
         h.curvature(self.k, self.eps or 0.0)
+
+    # A stream of clouds: the all-gather of the next cloud runs (RCCL's own stream) while the kernels of the
+    # current one run on the handle's stream.  Two gather buffers alternate.
+    def begin_exchange(self, local_dev, out):
+        """Start the all-gather of ``local_dev`` (this rank's (N/G,3) device shard) into ``out`` ((N,3) device)."""
+        import torch.distributed as dist
+        return dist.all_gather_into_tensor(out, local_dev, async_op=True)
+
+    def end_exchange(self, ticket, out):
+        """Block until the exchange started by ``begin_exchange`` has filled ``out``."""
+        import torch
+        ticket.wait()
+        torch.cuda.current_stream(out.device).synchronize()
+        return out
 
     def download(self):
         _, K, H, _ = self.handle.get_fit(self.lo, self.hi, coefs=False, H2=False)

@@ -556,3 +556,20 @@ def test_neighbor_study_on_a_plane_converges_low(gpu):
     sample = np.random.randint(0, 5000, 40)
     ref, _ = oracle.neighbor_study(pts, sample)
     assert res == ref
+
+
+def test_distributed_step_on_one_rank(gpu, tmp_path):
+    """The multi-GPU code path of bench.py (RCCL all-gather into a device buffer, zero-copy hand-over, owned-range
+    sweep, double-buffered exchange) with a world of one rank.  Runs in a child process: torch has to be loaded
+    before libpct_hip.so there (one HIP runtime per process), which this test process cannot arrange any more."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PCT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(v, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+                        "--points-per-gpu", "200000"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0
