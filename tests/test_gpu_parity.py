@@ -127,6 +127,54 @@ def test_brute_and_grid_agree_bitwise(gpu):
     assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
 
 
+def _stress_cloud(kind, rng, n):
+    if kind == "blobs":            # clusters of very different density
+        c = rng.uniform(-1, 1, size=(6, 3))
+        sc = 10.0 ** rng.uniform(-3.5, -0.5, size=6)
+        w = rng.integers(0, 6, size=n)
+        p = c[w] + rng.normal(size=(n, 3)) * sc[w, None]
+    elif kind == "outliers":       # a surface plus far points in every direction
+        p = np.stack([rng.uniform(-1, 1, n), rng.uniform(-1, 1, n), np.zeros(n)], 1)
+        p[:, 2] = 0.2 * np.sin(3 * p[:, 0]) * np.cos(2 * p[:, 1])
+        m = max(3, n // 2000)
+        p[rng.choice(n, m, replace=False)] = rng.normal(size=(m, 3)) * 10.0 ** rng.uniform(1, 2.5, size=(m, 1))
+    elif kind == "noisy_line":     # nearly one-dimensional
+        t = rng.uniform(0, 10, n)
+        p = np.stack([t, 0.3 * t, -0.1 * t], 1) + rng.normal(scale=1e-3, size=(n, 3))
+    elif kind == "shell_and_core": # a sphere with a dense core: many queries need more than the stencil
+        u = rng.normal(size=(n, 3))
+        u /= np.linalg.norm(u, axis=1)[:, None]
+        r = np.where(rng.uniform(size=n) < 0.3, rng.uniform(0, 0.01, n), 1.0)
+        p = u * r[:, None]
+    else:                          # "quantised": coordinates on a coarse lattice -> masses of exact ties
+        p = np.round(rng.uniform(-1, 1, size=(n, 3)) * 40) / 40
+        p[:, 2] = np.round(0.3 * np.sin(p[:, 0] * 3) * 40) / 40
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+@pytest.mark.parametrize("kind", ["blobs", "outliers", "noisy_line", "shell_and_core", "quantised"])
+def test_grid_sweep_equals_exhaustive_sweep_on_hostile_clouds(gpu, kind):
+    """Cell list (trimmed box, clamped outliers, fast + exact sweeps, owned-range culling) against the
+    exhaustive sweep of the same library, bit for bit, on clouds built to break a uniform grid.  The
+    exhaustive sweep itself is pinned to the oracle by the tests above."""
+    capi = gpu["capi"]
+    for n, k, eps in ((20_000, 30, 0.0), (12_000, 70, 0.0), (15_000, 25, 0.05)):
+        pts = _stress_cloud(kind, np.random.default_rng([len(kind), n]), n)
+        h = capi.Handle(0)
+        h.set_points(pts)
+        h.knn(k, eps=eps, algo=capi.KNN_BRUTE)
+        ib, db, cb = h.get_neighbors(0, n, want_count=True)
+        h.knn(k, eps=eps, algo=capi.KNN_GRID)
+        ig, dg, cg = h.get_neighbors(0, n, want_count=True)
+        assert np.array_equal(ib, ig) and np.array_equal(db, dg) and np.array_equal(cb, cg), (kind, n, k, eps)
+        lo, hi = n // 3, n // 3 + n // 4           # a shard in the middle
+        h.set_query_range(lo, hi)
+        h.knn(k, eps=eps, algo=capi.KNN_GRID)
+        i2, d2, c2 = h.get_neighbors(lo, hi, want_count=True)
+        assert np.array_equal(i2, ib[lo:hi]) and np.array_equal(d2, db[lo:hi]) and np.array_equal(c2, cb[lo:hi])
+        h.close()
+
+
 @pytest.mark.parametrize("k", [20, 50, 100])
 def test_exact_sweep_matches_fast_sweep(gpu, k):
     """The float-key fast sweep (+ redo of flagged queries) and the all-exact sweep agree bit for bit."""
