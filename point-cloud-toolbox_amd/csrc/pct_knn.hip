@@ -517,8 +517,12 @@ __device__ __forceinline__ void fast_sort_from(FastK<R>& t) {
     if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2, DESC>(t);
 }
 
+// waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
+// R = 1: 6 blocks x 4 waves x 6.25 KiB, R = 2: 4 blocks x 4 waves x 9.5 KiB)
+template <int R> constexpr int kFastWaves = 4;
+
 template <int R>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
+__global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
 #ifndef PCT_STAGE_CAP2
@@ -528,14 +532,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     constexpr int SLOT_BITS = R == 1 ? 9 : 10;
     constexpr int KEY_BITS = 32 - SLOT_BITS;
     static_assert(CAP <= (1 << SLOT_BITS), "slot field too narrow");
-    __shared__ float s_cx[kWavesPerBlock][CAP];        // staged stencil, structure of arrays:
-    __shared__ float s_cy[kWavesPerBlock][CAP];        // 12 B per candidate
-    __shared__ float s_cz[kWavesPerBlock][CAP];
-    __shared__ unsigned s_pend[kWavesPerBlock][64 * R + 64];
+    __shared__ float s_cx[kFastWaves<R>][CAP];        // staged stencil, structure of arrays:
+    __shared__ float s_cy[kFastWaves<R>][CAP];        // 12 B per candidate
+    __shared__ float s_cz[kFastWaves<R>][CAP];
+    __shared__ unsigned s_pend[kFastWaves<R>][64 * R];
+    __shared__ int s_offc[kFastWaves<R>][16];          // sorted position - flat slot, per non-empty run
+#if defined(PCT_LDS_PAD)
+    __shared__ volatile char s_padx[PCT_LDS_PAD];
+    if (threadIdx.x == 0) s_padx[PCT_LDS_PAD - 1] = 1;
+#endif
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
-    const int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w;
+    const int64_t item = (int64_t)blockIdx.x * kFastWaves<R> + w;
     if (item >= n_items) return;
 
     const pct_grid g = a.g;
@@ -556,6 +565,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
     float* cand_y = s_cy[w];
     float* cand_z = s_cz[w];
     unsigned* pend = s_pend[w];
+    int* offc = s_offc[w];
     int run_s = 0, run_len = 0;
     if (lane < 9) {
         const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
@@ -572,14 +582,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         my_q = a.pts[qs + lane];
         if (a.ptsd) my_qd = a.ptsd[qs + lane];
     }
-    int pre[10], off[9];
-    pre[0] = 0;
+    // exclusive prefix of the run lengths over lanes 0..8 = first flat slot of every run; m = staged candidates
+    int my_pre = 0, m = 0;
+    {
+        int acc = 0;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        pre[t + 1] = pre[t] + __builtin_amdgcn_readlane(run_len, t);
-        off[t] = __builtin_amdgcn_readlane(run_s, t) - pre[t];           // sorted position = flat slot + off[t]
+        for (int t = 0; t < 9; ++t) {
+            my_pre = lane == t ? acc : my_pre;
+            acc += __builtin_amdgcn_readlane(run_len, t);
+        }
+        m = acc;
     }
-    const int m = pre[9];
     unsigned long long n_flush = 0, n_step = 0, n_redo = 0;
 
     if (m > CAP) {
@@ -595,18 +608,47 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
         return;
     }
 
-    // ---- copy the runs as one flat range: all global loads of the item are in flight together
+    // ---- copy the runs as one flat range: all global loads of the item are in flight together.
+    // Flat slot j belongs to the u-th non-empty run, u = (number of run starts <= j) - 1.  The run starts are
+    // marked in a CAP-bit string in LDS (the list area is free here), so that a batch of 64 slots gets its u
+    // from one 64-bit word and a masked bit count instead of eight compares; offc[u] = sorted position - flat
+    // slot of run u.  u is also remembered in 4 bits per staged slot (run_code: this lane's slots lane,
+    // 64 + lane, ...) for the store phase, which turns a slot back into a sorted position with one cross-lane
+    // read and one LDS read.
+    unsigned run_code[(CAP / 64 + 7) / 8];
+#pragma unroll
+    for (int i = 0; i < (CAP / 64 + 7) / 8; ++i) run_code[i] = 0u;
     {
+        unsigned* bits = pend;
+        static_assert(CAP / 32 <= 64 * R, "bit string does not fit the list area");
+        if (lane < CAP / 32) bits[lane] = 0u;
+        wave_lds_sync();
+        const bool nonempty = lane < 9 && run_len > 0;
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
+        if (nonempty) {
+            atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
+            offc[__builtin_amdgcn_mbcnt_lo((unsigned)ne, 0)] = run_s - my_pre;     // lanes 0..8: low word only
+        }
+        wave_lds_sync();
         float4 tmp[CAP / 64];
+        int ubase = -1;
 #pragma unroll
         for (int b = 0; b < CAP / 64; ++b) {
-            const int j = b * 64 + lane;
-            int o = off[0];
-#pragma unroll
-            for (int t = 1; t < 9; ++t) o = j >= pre[t] ? off[t] : o;
             tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (j < m) tmp[b] = a.pts[j + o];
+            if (b * 64 < m) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b]);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b + 1]);
+                const unsigned long long B = ((unsigned long long)hi << 32) | lo;
+                const unsigned long long S = B >> 1;               // starts <= lane  =  starts of (B >> 1) below lane, + bit 0
+                const int c0 = ubase + (int)(lo & 1u);
+                const int u = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(S >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)S, (unsigned)c0));
+                ubase += (int)__popcll(B);
+                const int j = b * 64 + lane;
+                run_code[b >> 3] |= (unsigned)u << (4 * (b & 7));
+                if (j < m) tmp[b] = a.pts[j + offc[u]];
+            }
         }
+        wave_lds_sync();                      // the bit string is dead: the list area goes back to the queries
 #pragma unroll
         for (int b = 0; b < CAP / 64; ++b) {
             const int j = b * 64 + lane;
@@ -664,7 +706,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
                 if (slot < m) {
                     const double dx = (double)cand_x[slot] - qx, dy = (double)cand_y[slot] - qy, dz = (double)cand_z[slot] - qz;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max);
+                    if (d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max - 1u);   // key_max itself: padding only
                 }
                 total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
                 ++n_step;
@@ -746,7 +788,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
             amb |= need > gkey;
             // a saturated key (a point clamped into a boundary cell from outside the grid box) says nothing
             // about the true distance
-            amb |= tau != kPadElem && tkey >= key_max;
+            amb |= tau != kPadElem && tkey >= key_max - 1u;
         }
         // ---- neighbours with equal keys inside the first k+2 entries: order not proven
         {
@@ -774,19 +816,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_fast(KnnArgs a, con
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             const int i = lane + 64 * r;
+            const unsigned e = best.e[r];
+            const bool real = e != kPadElem;
+            const int j = (int)(e & ((1u << SLOT_BITS) - 1u));       // staged slot (anything for padding)
+            // sorted position of slot j = j + offset of its run.  The cross-lane reads need every lane active:
+            // they stay outside the divergent part.
+            unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+            if constexpr ((CAP / 64 + 7) / 8 > 1) {
+                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
+                code = (j >> 9) ? hi : code;
+            }
+            const unsigned t = (code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u;       // index of the slot's run
+            const int pos_real = j + offc[t];
             if (i >= 1 && i <= k) {
-                const unsigned e = best.e[r];
-                const bool real = e != kPadElem;
                 int pos = -1;
                 float dist = INFINITY;
                 if (real) {
-                    const int j = (int)(e & ((1u << SLOT_BITS) - 1u));
                     const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
-                    int o = off[0];
-#pragma unroll
-                    for (int t = 1; t < 9; ++t) o = j >= pre[t] ? off[t] : o;
-                    pos = j + o;                                      // sorted position of staged slot j
                     dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
+                    pos = pos_real;
                 }
                 a.nbr_pos[(int64_t)row * a.pitch + (i - 1)] = pos;
                 a.nbr_dist[(int64_t)row * a.pitch + (i - 1)] = dist;
@@ -948,17 +996,17 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     int* redo_count = (int*)ctx->counters.p + 14;            // counters buffer: 8 x u64, last int pair reserved
     int* redo = (int*)ctx->redo.p;
     const dim3 block(64 * kWavesPerBlock);
-    if (!exact_only) {
-        const int blocks = (int)((ctx->n_items + kWavesPerBlock - 1) / kWavesPerBlock);
-        if (blocks > 0) {
-            if (k + 1 <= 64)
-                hipLaunchKernelGGL(k_knn_fast<1>, dim3(blocks), block, 0, ctx->stream, a, (const int2*)ctx->occ.p,
-                                   ctx->n_items, ctx->items_q, redo, redo_count);
-            else
-                hipLaunchKernelGGL(k_knn_fast<2>, dim3(blocks), block, 0, ctx->stream, a, (const int2*)ctx->occ.p,
-                                   ctx->n_items, ctx->items_q, redo, redo_count);
-            PCT_HIP(ctx, hipGetLastError());
+    if (!exact_only && ctx->n_items > 0) {
+        if (k + 1 <= 64) {
+            constexpr int W = kFastWaves<1>;
+            hipLaunchKernelGGL(k_knn_fast<1>, dim3((unsigned)((ctx->n_items + W - 1) / W)), dim3(64 * W), 0, ctx->stream, a,
+                               (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q, redo, redo_count);
+        } else {
+            constexpr int W = kFastWaves<2>;
+            hipLaunchKernelGGL(k_knn_fast<2>, dim3((unsigned)((ctx->n_items + W - 1) / W)), dim3(64 * W), 0, ctx->stream, a,
+                               (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q, redo, redo_count);
         }
+        PCT_HIP(ctx, hipGetLastError());
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
     // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
