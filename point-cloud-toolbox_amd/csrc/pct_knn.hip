@@ -521,7 +521,9 @@ __device__ __forceinline__ void fast_sort_from(FastK<R>& t) {
 // R = 1: 6 blocks x 4 waves x 6.25 KiB, R = 2: 4 blocks x 4 waves x 9.5 KiB)
 template <int R> constexpr int kFastWaves = 4;
 
-template <int R>
+// EPS = the hybrid eps-ball query is on (candidates beyond eps do not count); without it every staged slot is a
+// candidate and the per-batch eps compares and candidate counts drop out.
+template <int R, bool EPS>
 __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
@@ -657,7 +659,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     }
     wave_lds_sync();
     const int k = a.k;
-    const double eps2 = a.eps2;
+    const double eps2 = EPS ? a.eps2 : (double)INFINITY;
     const double scale = (double)(1u << KEY_BITS) / (12.1 * g.cell * g.cell);
     const unsigned key_max = (1u << KEY_BITS) - 1u;
     // Per query, the largest key the stencil can vouch for: lane l evaluates query l once per item (the radius
@@ -676,7 +678,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
         my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     // ceil(eps^2 * scale): the whole eps ball must be inside the guaranteed radius too
-    const unsigned eps_key = eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
+    const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
 
     constexpr int NB = CAP / 64;             // candidate registers per lane: slot = b * 64 + lane
     constexpr int LIST = 64 * R;             // capacity of the sorted list
@@ -697,7 +699,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
 
         // ---- keys of ALL staged candidates, in registers (0xFFFFFFFF = not a candidate) ----------------------
         unsigned key[NB];
-        int total = 0;
+        int total = EPS ? 0 : m;
 #pragma unroll
         for (int b = 0; b < NB; ++b) {
             key[b] = 0xFFFFFFFFu;
@@ -706,9 +708,9 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 if (slot < m) {
                     const double dx = (double)cand_x[slot] - qx, dy = (double)cand_y[slot] - qy, dz = (double)cand_z[slot] - qz;
                     const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max - 1u);   // key_max itself: padding only
+                    if (!EPS || d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max - 1u);   // key_max itself: padding only
                 }
-                total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
+                if constexpr (EPS) total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
                 ++n_step;
             }
         }
@@ -732,13 +734,17 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 if (c >= k + 1 && c <= LIST) { T = t; cnt = c; found = true; break; }
                 if (c < k + 1) lo = t; else hi = t;
                 if (hi - lo <= 1u) break;                  // a pile of equal keys straddles the window
-                const float guess = (float)t * target / (float)(c > 0 ? c : 1);
+                const float guess = (float)t * target * __builtin_amdgcn_rcpf((float)(c > 0 ? c : 1));   // a guess: 1 ulp is plenty
                 unsigned nt = guess >= 4294967040.f ? hi : (unsigned)guess;
                 if (c == 0) nt = t * 4u > t ? t * 4u : hi;
                 if (nt <= lo || nt >= hi) nt = lo + (hi - lo) / 2u;
                 t = nt;
             }
-            amb |= !found;
+            if (!found) {                                   // no usable threshold: the exact sweep takes the query
+                if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+                ++n_redo;
+                continue;
+            }
         }
         t_prev = T <= key_max ? T : t_prev;
 
@@ -754,7 +760,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
                     if (pass) {
                         const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        if (at < LIST) pend[at] = (key[b] << SLOT_BITS) | (unsigned)(b * 64 + lane);
+                        pend[at] = (key[b] << SLOT_BITS) | (unsigned)(b * 64 + lane);      // at < cnt <= LIST
                     }
                     base += (int)__popcll(mask);
                 }
@@ -997,15 +1003,17 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     int* redo = (int*)ctx->redo.p;
     const dim3 block(64 * kWavesPerBlock);
     if (!exact_only && ctx->n_items > 0) {
-        if (k + 1 <= 64) {
-            constexpr int W = kFastWaves<1>;
-            hipLaunchKernelGGL(k_knn_fast<1>, dim3((unsigned)((ctx->n_items + W - 1) / W)), dim3(64 * W), 0, ctx->stream, a,
-                               (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q, redo, redo_count);
-        } else {
-            constexpr int W = kFastWaves<2>;
-            hipLaunchKernelGGL(k_knn_fast<2>, dim3((unsigned)((ctx->n_items + W - 1) / W)), dim3(64 * W), 0, ctx->stream, a,
-                               (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q, redo, redo_count);
-        }
+        const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
+        const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
+        const int2* items = (const int2*)ctx->occ.p;
+        if (k + 1 <= 64 && !(eps > 0))
+            hipLaunchKernelGGL((k_knn_fast<1, false>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
+        else if (k + 1 <= 64)
+            hipLaunchKernelGGL((k_knn_fast<1, true>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
+        else if (!(eps > 0))
+            hipLaunchKernelGGL((k_knn_fast<2, false>), grid2, block2, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
+        else
+            hipLaunchKernelGGL((k_knn_fast<2, true>), grid2, block2, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
         PCT_HIP(ctx, hipGetLastError());
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
