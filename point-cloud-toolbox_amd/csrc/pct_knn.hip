@@ -476,16 +476,53 @@ struct FastK {
     unsigned e[R];
 };
 
-template <int R, int SIZE, int STRIDE, bool DESC>
-__device__ __forceinline__ void fast_level(FastK<R>& t) {
-    const int lane = lane_id();
+// Direction of every lane-to-lane compare-exchange level as one bit per level and lane (1 = this lane keeps the
+// larger element): a compile-time table, loaded once per wave.  With it a level is  partner move, v_bfe_i32,
+// v_med3_u32  -- med3(a, b, 0) = min, med3(a, b, ~0) = max -- and needs no per-level lane mask in scalar registers
+// (21 masks = 42 SGPRs would not fit next to the rest of the kernel).
+constexpr int lane_level_index(int size, int stride) {      // ordinal of (size, stride < 64) in network order
+    int idx = 0;
+    for (int sz = 2; sz <= 128; sz *= 2)
+        for (int st = sz / 2; st >= 1; st /= 2) {
+            if (st >= 64) continue;
+            if (sz == size && st == stride) return idx;
+            ++idx;
+        }
+    return -1;
+}
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct SortSelTable { unsigned v[2][64]; };
+constexpr SortSelTable make_sort_sel() {
+    SortSelTable t{};
+    for (int r = 0; r < 2; ++r)
+        for (int lane = 0; lane < 64; ++lane) {
+            unsigned bits = 0;
+            for (int sz = 2; sz <= 128; sz *= 2)
+                for (int st = sz / 2; st >= 1; st /= 2) {
+                    if (st >= 64) continue;
+                    const bool asc = ((lane + 64 * r) & sz) == 0;
+                    const bool keep_min = ((lane & st) == 0) == asc;
+                    if (!keep_min) bits |= 1u << lane_level_index(sz, st);
+                }
+            t.v[r][lane] = bits;
+        }
+    return t;
+}
+__constant__ const SortSelTable kSortSel = make_sort_sel();
+
+template <int R, int SIZE, int STRIDE>
+__device__ __forceinline__ void fast_level(FastK<R>& t, const unsigned (&dir)[R]) {
     if constexpr (STRIDE >= 64) {
         constexpr int ds = STRIDE >> 6;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             if ((r & ds) == 0 && (r | ds) < R) {
                 const int r2 = r | ds;
-                const bool asc = (((64 * r) & SIZE) == 0) != DESC;     // SIZE >= 128 here: depends on the slot only
+                const bool asc = ((64 * r) & SIZE) == 0;                // SIZE >= 128 here: depends on the slot only
                 const unsigned lo = min(t.e[r], t.e[r2]);
                 const unsigned hi = max(t.e[r], t.e[r2]);
                 t.e[r] = asc ? lo : hi;
@@ -493,28 +530,41 @@ __device__ __forceinline__ void fast_level(FastK<R>& t) {
             }
         }
     } else {
+        constexpr int idx = lane_level_index(SIZE, STRIDE);
+        static_assert(idx >= 0 && idx < 32, "level table");
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const unsigned pk = (unsigned)lane_xor<STRIDE>((int)t.e[r]);
-            const bool asc = (((lane + 64 * r) & SIZE) == 0) != DESC;
-            const bool keep_min = ((lane & STRIDE) == 0) == asc;        // lane-constant: hoisted into a scalar mask
-            // elements are unique (slot bits), so min/max IS the compare-exchange; no VALU->SALU->VALU round trip
-            const unsigned lo = min(t.e[r], pk), hi = max(t.e[r], pk);
-            t.e[r] = keep_min ? lo : hi;
+            // 0 -> min, ~0 -> max.  volatile: the compiler would otherwise hoist all 21 extractions out of the query
+            // loop and hold them in 21 VGPRs (an occupancy step) to save one instruction per level
+            unsigned sel;
+            asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(dir[r]), "n"(idx));
+            if constexpr (STRIDE == 16) {
+                // after the swap the two results hold {own, partner} in an order that depends on the lane; as a
+                // set that is all a compare-exchange needs
+                const auto p = __builtin_amdgcn_permlane16_swap(t.e[r], t.e[r], false, false);
+                t.e[r] = umed3(p[0], p[1], sel);
+            } else if constexpr (STRIDE == 32) {
+                const auto p = __builtin_amdgcn_permlane32_swap(t.e[r], t.e[r], false, false);
+                t.e[r] = umed3(p[0], p[1], sel);
+            } else {
+                const unsigned pk = (unsigned)lane_xor<STRIDE>((int)t.e[r]);
+                t.e[r] = umed3(t.e[r], pk, sel);
+            }
         }
     }
 }
 
-template <int R, int SIZE, int STRIDE, bool DESC>
-__device__ __forceinline__ void fast_strides(FastK<R>& t) {
-    fast_level<R, SIZE, STRIDE, DESC>(t);
-    if constexpr (STRIDE > 1) fast_strides<R, SIZE, STRIDE / 2, DESC>(t);
+template <int R, int SIZE, int STRIDE>
+__device__ __forceinline__ void fast_strides(FastK<R>& t, const unsigned (&dir)[R]) {
+    fast_level<R, SIZE, STRIDE>(t, dir);
+    if constexpr (STRIDE > 1) fast_strides<R, SIZE, STRIDE / 2>(t, dir);
 }
 
-template <int R, int SIZE, bool DESC>
-__device__ __forceinline__ void fast_sort_from(FastK<R>& t) {
-    fast_strides<R, SIZE, SIZE / 2, DESC>(t);
-    if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2, DESC>(t);
+// ascending sort of 64 R elements, starting from sorted runs of SIZE / 2
+template <int R, int SIZE>
+__device__ __forceinline__ void fast_sort_from(FastK<R>& t, const unsigned (&dir)[R]) {
+    fast_strides<R, SIZE, SIZE / 2>(t, dir);
+    if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2>(t, dir);
 }
 
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
@@ -548,6 +598,9 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     const int lane = lane_id();
     const int64_t item = (int64_t)blockIdx.x * kFastWaves<R> + w;
     if (item >= n_items) return;
+    unsigned sort_dir[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) sort_dir[r] = kSortSel.v[r][lane];
 
     const pct_grid g = a.g;
     const int* __restrict__ cs = a.cell_start;
@@ -773,7 +826,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 best.e[r] = i < have ? pend[i] : kPadElem;
             }
             wave_lds_sync();
-            fast_sort_from<R, 2, false>(best);             // ascending
+            fast_sort_from<R, 2>(best, sort_dir);          // ascending
             ++n_flush;
         }
         unsigned tau;                        // element k of the list = the (k+1)-th nearest (padding if fewer exist)
