@@ -573,7 +573,15 @@ template <int R> constexpr int kFastWaves = 4;
 
 // EPS = the hybrid eps-ball query is on (candidates beyond eps do not count); without it every staged slot is a
 // candidate and the per-batch eps compares and candidate counts drop out.
-template <int R, bool EPS>
+// PRE = float32 pre-selection (clouds whose query coordinates are the float32 tree coordinates): the threshold
+// that cuts the staged candidates down to <= 64 R is searched on squared distances computed in packed float32
+// (two candidates per instruction), and only the survivors get the exact fp64 distance and a key.  A float32
+// squared distance of float32 points is within 5 * 2^-24 relative of the exact one (the difference of two
+// floats is rounded once, then one product and two fused multiply-adds), so a candidate that was cut has an
+// exact squared distance >= T (1 - 2^-20): the query is accepted only if its (k+1)-th exact key lies below that.
+typedef float float2v __attribute__((ext_vector_type(2)));
+
+template <int R, bool EPS, bool PRE>
 __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
@@ -589,10 +597,6 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     __shared__ float s_cz[kFastWaves<R>][CAP];
     __shared__ unsigned s_pend[kFastWaves<R>][64 * R];
     __shared__ int s_offc[kFastWaves<R>][16];          // sorted position - flat slot, per non-empty run
-#if defined(PCT_LDS_PAD)
-    __shared__ volatile char s_padx[PCT_LDS_PAD];
-    if (threadIdx.x == 0) s_padx[PCT_LDS_PAD - 1] = 1;
-#endif
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
@@ -707,7 +711,12 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
 #pragma unroll
         for (int b = 0; b < CAP / 64; ++b) {
             const int j = b * 64 + lane;
-            if (j < m) { cand_x[j] = tmp[b].x; cand_y[j] = tmp[b].y; cand_z[j] = tmp[b].z; }
+            if (j < m) {
+                cand_x[j] = tmp[b].x; cand_y[j] = tmp[b].y; cand_z[j] = tmp[b].z;
+            } else if (PRE && (b & ~1) * 64 < m) {
+                // the pre-selection works on pairs of batches: unused slots sit at +inf and never pass a threshold
+                cand_x[j] = INFINITY; cand_y[j] = 0.f; cand_z[j] = 0.f;
+            }
         }
     }
     wave_lds_sync();
@@ -736,6 +745,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     constexpr int NB = CAP / 64;             // candidate registers per lane: slot = b * 64 + lane
     constexpr int LIST = 64 * R;             // capacity of the sorted list
     unsigned t_prev = 0;                     // threshold of the previous query of this item (0 = none yet)
+    float t_prev_f = 0.f;                    // same for the float32 pre-selection
+    const float cell2f = (float)(g.cell * g.cell);
+    // eps^2 rounded up generously in float32: everything inside the eps ball passes the pre-selection, the exact
+    // test follows on the survivors
+    const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
 
     for (int qi = 0; qi < nq; ++qi) {
         const int row = row0 + qi;
@@ -750,84 +764,180 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             qz = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
         }
 
-        // ---- keys of ALL staged candidates, in registers (0xFFFFFFFF = not a candidate) ----------------------
-        unsigned key[NB];
-        int total = EPS ? 0 : m;
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            key[b] = 0xFFFFFFFFu;
-            if (b * 64 < m) {
-                const int slot = b * 64 + lane;
-                if (slot < m) {
-                    const double dx = (double)cand_x[slot] - qx, dy = (double)cand_y[slot] - qy, dz = (double)cand_z[slot] - qz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (!EPS || d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max - 1u);   // key_max itself: padding only
-                }
-                if constexpr (EPS) total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
-                ++n_step;
-            }
-        }
-
-        // ---- threshold T with k+1 <= #(key < T) <= LIST: a few ballot-count trials.  Counts grow about linearly in
-        // d^2 (= in the key) on a surface, so a secant step from the previous query's threshold usually lands at once.
-        unsigned T = key_max + 1u;           // "everything"
-        int cnt = total;
+        FastK<R> best;
         bool amb = false;                    // per-lane: something this kernel cannot prove exact
-        if (total > LIST) {
-            unsigned lo = 0u, hi = key_max + 1u;          // count(lo) < k+1 ; count(hi) > LIST
-            unsigned t = t_prev ? t_prev : (unsigned)((double)(1u << KEY_BITS) / 12.1);   // first guess: one cell edge
-            const float target = 0.5f * (float)(k + 1 + LIST);
-            bool found = false;
-#pragma unroll 1
-            for (int trial = 0; trial < 16; ++trial) {
-                int c = 0;
+        unsigned bkey = 0xFFFFFFFFu;         // exact keys of the candidates the pre-selection cut are >= bkey
+        if constexpr (PRE) {
+            const float fqx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+            const float fqy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+            const float fqz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+            // ---- float32 squared distances of ALL staged candidates, two batches per packed instruction ---------
+            float appr[NB];
+#pragma unroll
+            for (int p2 = 0; p2 < NB / 2; ++p2) {
+                appr[2 * p2] = INFINITY;
+                appr[2 * p2 + 1] = INFINITY;
+                if (p2 * 128 < m) {
+                    const int sa = p2 * 128 + lane, sb = sa + 64;
+                    const float2v vx = {cand_x[sa], cand_x[sb]}, vy = {cand_y[sa], cand_y[sb]}, vz = {cand_z[sa], cand_z[sb]};
+                    const float2v dx = vx - fqx, dy = vy - fqy, dz = vz - fqz;
+                    float2v d = dx * dx;
+                    d = __builtin_elementwise_fma(dy, dy, d);
+                    d = __builtin_elementwise_fma(dz, dz, d);
+                    appr[2 * p2] = d.x;
+                    appr[2 * p2 + 1] = d.y;
+                    n_step += 2;
+                }
+            }
+            // ---- threshold T with k+1 <= #(appr < T) <= LIST; never beyond the eps ball -----------------------------
+            float T = EPS ? eps2a : INFINITY;
+            int total = m;
+            if constexpr (EPS) {
+                total = 0;
 #pragma unroll
                 for (int b = 0; b < NB; ++b)
-                    if (b * 64 < m) c += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] < t));
-                if (c >= k + 1 && c <= LIST) { T = t; cnt = c; found = true; break; }
-                if (c < k + 1) lo = t; else hi = t;
-                if (hi - lo <= 1u) break;                  // a pile of equal keys straddles the window
-                const float guess = (float)t * target * __builtin_amdgcn_rcpf((float)(c > 0 ? c : 1));   // a guess: 1 ulp is plenty
-                unsigned nt = guess >= 4294967040.f ? hi : (unsigned)guess;
-                if (c == 0) nt = t * 4u > t ? t * 4u : hi;
-                if (nt <= lo || nt >= hi) nt = lo + (hi - lo) / 2u;
-                t = nt;
+                    if ((b & ~1) * 64 < m) total += (int)__popcll(__builtin_amdgcn_ballot_w64(appr[b] < T));
             }
-            if (!found) {                                   // no usable threshold: the exact sweep takes the query
-                if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
-                ++n_redo;
-                continue;
+            int cnt = total;
+            if (total > LIST) {
+                float lo = 0.f, hi = T;                        // count(lo) < k+1 ; count(hi) > LIST
+                float t = t_prev_f > 0.f ? t_prev_f : cell2f;  // first guess: one cell edge
+                if (!(t < hi)) t = 0.5f * hi;
+                const float target = 0.5f * (float)(k + 1 + LIST);
+                bool found = false;
+#pragma unroll 1
+                for (int trial = 0; trial < 16; ++trial) {
+                    int c = 0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        if ((b & ~1) * 64 < m) c += (int)__popcll(__builtin_amdgcn_ballot_w64(appr[b] < t));
+                    if (c >= k + 1 && c <= LIST) { T = t; cnt = c; found = true; break; }
+                    if (c < k + 1) lo = t; else hi = t;
+                    float nt = c > 0 ? t * target * __builtin_amdgcn_rcpf((float)c) : 4.f * t;
+                    if (!(nt > lo && nt < hi)) nt = hi < INFINITY ? 0.5f * (lo + hi) : 2.f * lo;
+                    nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));   // uniform by construction
+                    if (!(nt > lo && nt < hi)) break;          // no float left between: a pile of equal distances
+                    t = nt;
+                }
+                if (!found || !(T >= 1e-30f)) {                // no usable threshold: the exact sweep takes the query
+                    if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+                    ++n_redo;
+                    continue;
+                }
+                t_prev_f = T;
+                bkey = (unsigned)fmin((double)T * (1.0 - 0x1p-20) * scale, 4294967294.0);
             }
-        }
-        t_prev = T <= key_max ? T : t_prev;
-
-        // ---- compact the selected candidates (all of them when there are <= LIST) and sort them ONCE ----------
-        FastK<R> best;
-        {
-            int base = 0;
-            wave_lds_sync();
+            // ---- compact the slots of the survivors, then exact keys for them only ---------------------------------
+            {
+                int base = 0;
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if ((b & ~1) * 64 < m) {
+                        const bool pass = appr[b] < T;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                        if (pass) {
+                            const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            pend[at] = (unsigned)(b * 64 + lane);                       // at < cnt <= LIST
+                        }
+                        base += (int)__popcll(mask);
+                    }
+                }
+                wave_lds_sync();
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    unsigned e = kPadElem;
+                    if (i < cnt) {
+                        const int j = (int)pend[i];
+                        const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (!EPS || d2 < eps2) e = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)j;
+                    }
+                    best.e[r] = e;
+                }
+                wave_lds_sync();
+                fast_sort_from<R, 2>(best, sort_dir);          // ascending
+                ++n_flush;
+            }
+        } else {
+            // ---- keys of ALL staged candidates, in registers (0xFFFFFFFF = not a candidate) ----------------------
+            unsigned key[NB];
+            int total = EPS ? 0 : m;
 #pragma unroll
             for (int b = 0; b < NB; ++b) {
+                key[b] = 0xFFFFFFFFu;
                 if (b * 64 < m) {
-                    const bool pass = key[b] < T;
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-                    if (pass) {
-                        const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        pend[at] = (key[b] << SLOT_BITS) | (unsigned)(b * 64 + lane);      // at < cnt <= LIST
+                    const int slot = b * 64 + lane;
+                    if (slot < m) {
+                        const double dx = (double)cand_x[slot] - qx, dy = (double)cand_y[slot] - qy, dz = (double)cand_z[slot] - qz;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (!EPS || d2 < eps2) key[b] = min((unsigned)(d2 * scale), key_max - 1u);   // key_max itself: padding only
                     }
-                    base += (int)__popcll(mask);
+                    if constexpr (EPS) total += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] != 0xFFFFFFFFu));
+                    ++n_step;
                 }
             }
-            wave_lds_sync();
-            const int have = cnt < LIST ? cnt : LIST;
+
+            // ---- threshold T with k+1 <= #(key < T) <= LIST: a few ballot-count trials.  Counts grow about linearly in
+            // d^2 (= in the key) on a surface, so a secant step from the previous query's threshold usually lands at once.
+            unsigned T = key_max + 1u;           // "everything"
+            int cnt = total;
+            if (total > LIST) {
+                unsigned lo = 0u, hi = key_max + 1u;          // count(lo) < k+1 ; count(hi) > LIST
+                unsigned t = t_prev ? t_prev : (unsigned)((double)(1u << KEY_BITS) / 12.1);   // first guess: one cell edge
+                const float target = 0.5f * (float)(k + 1 + LIST);
+                bool found = false;
+#pragma unroll 1
+                for (int trial = 0; trial < 16; ++trial) {
+                    int c = 0;
 #pragma unroll
-            for (int r = 0; r < R; ++r) {
-                const int i = lane + 64 * r;
-                best.e[r] = i < have ? pend[i] : kPadElem;
+                    for (int b = 0; b < NB; ++b)
+                        if (b * 64 < m) c += (int)__popcll(__builtin_amdgcn_ballot_w64(key[b] < t));
+                    if (c >= k + 1 && c <= LIST) { T = t; cnt = c; found = true; break; }
+                    if (c < k + 1) lo = t; else hi = t;
+                    if (hi - lo <= 1u) break;                  // a pile of equal keys straddles the window
+                    const float guess = (float)t * target * __builtin_amdgcn_rcpf((float)(c > 0 ? c : 1));   // a guess: 1 ulp is plenty
+                    unsigned nt = guess >= 4294967040.f ? hi : (unsigned)guess;
+                    if (c == 0) nt = t * 4u > t ? t * 4u : hi;
+                    if (nt <= lo || nt >= hi) nt = lo + (hi - lo) / 2u;
+                    t = nt;
+                }
+                if (!found) {                                   // no usable threshold: the exact sweep takes the query
+                    if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+                    ++n_redo;
+                    continue;
+                }
             }
-            wave_lds_sync();
-            fast_sort_from<R, 2>(best, sort_dir);          // ascending
-            ++n_flush;
+            t_prev = T <= key_max ? T : t_prev;
+
+            // ---- compact the selected candidates (all of them when there are <= LIST) and sort them ONCE ----------
+            {
+                int base = 0;
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if (b * 64 < m) {
+                        const bool pass = key[b] < T;
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                        if (pass) {
+                            const int at = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            pend[at] = (key[b] << SLOT_BITS) | (unsigned)(b * 64 + lane);      // at < cnt <= LIST
+                        }
+                        base += (int)__popcll(mask);
+                    }
+                }
+                wave_lds_sync();
+                const int have = cnt < LIST ? cnt : LIST;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    best.e[r] = i < have ? pend[i] : kPadElem;
+                }
+                wave_lds_sync();
+                fast_sort_from<R, 2>(best, sort_dir);          // ascending
+                ++n_flush;
+            }
         }
         unsigned tau;                        // element k of the list = the (k+1)-th nearest (padding if fewer exist)
         {
@@ -844,7 +954,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             const unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
             const unsigned tkey = tau >> SLOT_BITS;
             const unsigned need = min(tau == kPadElem ? 0xFFFFFFFFu : tkey + 1u, eps_key);
-            amb |= need > gkey;
+            amb |= need > min(gkey, bkey);
             // a saturated key (a point clamped into a boundary cell from outside the grid box) says nothing
             // about the true distance
             amb |= tau != kPadElem && tkey >= key_max - 1u;
@@ -1059,14 +1169,18 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
         const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
         const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
         const int2* items = (const int2*)ctx->occ.p;
-        if (k + 1 <= 64 && !(eps > 0))
-            hipLaunchKernelGGL((k_knn_fast<1, false>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
-        else if (k + 1 <= 64)
-            hipLaunchKernelGGL((k_knn_fast<1, true>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
-        else if (!(eps > 0))
-            hipLaunchKernelGGL((k_knn_fast<2, false>), grid2, block2, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
-        else
-            hipLaunchKernelGGL((k_knn_fast<2, true>), grid2, block2, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count);
+        const bool e = eps > 0, pre = !ctx->has_f64, r1 = k + 1 <= 64;
+#define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
+    hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (r1 && !e && pre) PCT_FAST(1, false, true, grid1, block1);
+        else if (r1 && e && pre) PCT_FAST(1, true, true, grid1, block1);
+        else if (r1 && !e) PCT_FAST(1, false, false, grid1, block1);
+        else if (r1) PCT_FAST(1, true, false, grid1, block1);
+        else if (!e && pre) PCT_FAST(2, false, true, grid2, block2);
+        else if (e && pre) PCT_FAST(2, true, true, grid2, block2);
+        else if (!e) PCT_FAST(2, false, false, grid2, block2);
+        else PCT_FAST(2, true, false, grid2, block2);
+#undef PCT_FAST
         PCT_HIP(ctx, hipGetLastError());
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
