@@ -476,95 +476,96 @@ struct FastK {
     unsigned e[R];
 };
 
-// Direction of every lane-to-lane compare-exchange level as one bit per level and lane (1 = this lane keeps the
-// larger element): a compile-time table, loaded once per wave.  With it a level is  partner move, v_bfe_i32,
-// v_med3_u32  -- med3(a, b, 0) = min, med3(a, b, ~0) = max -- and needs no per-level lane mask in scalar registers
-// (21 masks = 42 SGPRs would not fit next to the rest of the kernel).
-constexpr int lane_level_index(int size, int stride) {      // ordinal of (size, stride < 64) in network order
-    int idx = 0;
-    for (int sz = 2; sz <= 128; sz *= 2)
-        for (int st = sz / 2; st >= 1; st /= 2) {
-            if (st >= 64) continue;
-            if (sz == size && st == stride) return idx;
-            ++idx;
-        }
-    return -1;
-}
+// ---------------------------------------------------------------------------
+// Sorting network of the fast sweep: bitonic merges in the "flip" form -- a merge of two ascending runs of
+// SIZE/2 first compares element i with element i ^ (SIZE - 1), then runs the half-cleaners of strides
+// SIZE/4 .. 1 -- in which EVERY compare-exchange leaves the smaller element at the lower index.  Which of the two
+// a lane keeps therefore depends only on one bit of its lane id: six lane-constant words sel[j] = -(bit j of
+// lane) serve all 21 (28) levels, and a level is  partner move + v_med3_u32  (med3(a, b, 0) = min,
+// med3(a, b, ~0) = max) with no per-level mask in scalar registers.  Partner moves: DPP for xor 1, 2, 3, 7, 8, 15,
+// two DPP moves for xor 4, v_permlane16/32_swap for xor 16 / 32 (the pair of results holds {own, partner} in
+// lane-dependent order -- as a set that is all a compare-exchange needs), ds_bpermute for the two wide flips.
+// ---------------------------------------------------------------------------
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c) {
     unsigned r;
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-struct SortSelTable { unsigned v[2][64]; };
-constexpr SortSelTable make_sort_sel() {
-    SortSelTable t{};
-    for (int r = 0; r < 2; ++r)
-        for (int lane = 0; lane < 64; ++lane) {
-            unsigned bits = 0;
-            for (int sz = 2; sz <= 128; sz *= 2)
-                for (int st = sz / 2; st >= 1; st /= 2) {
-                    if (st >= 64) continue;
-                    const bool asc = ((lane + 64 * r) & sz) == 0;
-                    const bool keep_min = ((lane & st) == 0) == asc;
-                    if (!keep_min) bits |= 1u << lane_level_index(sz, st);
-                }
-            t.v[r][lane] = bits;
-        }
-    return t;
-}
-__constant__ const SortSelTable kSortSel = make_sort_sel();
 
-template <int R, int SIZE, int STRIDE>
-__device__ __forceinline__ void fast_level(FastK<R>& t, const unsigned (&dir)[R]) {
-    if constexpr (STRIDE >= 64) {
-        constexpr int ds = STRIDE >> 6;
+struct SortLanes {
+    unsigned sel[6];     // sel[j] = all ones if bit j of the lane id is set
+    int a31, a63;        // byte addresses of lanes lane ^ 31, lane ^ 63 for ds_bpermute
+};
+
+__device__ __forceinline__ SortLanes make_sort_lanes() {
+    SortLanes c;
+    const int lane = lane_id();
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            if ((r & ds) == 0 && (r | ds) < R) {
-                const int r2 = r | ds;
-                const bool asc = ((64 * r) & SIZE) == 0;                // SIZE >= 128 here: depends on the slot only
-                const unsigned lo = min(t.e[r], t.e[r2]);
-                const unsigned hi = max(t.e[r], t.e[r2]);
-                t.e[r] = asc ? lo : hi;
-                t.e[r2] = asc ? hi : lo;
-            }
-        }
-    } else {
-        constexpr int idx = lane_level_index(SIZE, STRIDE);
-        static_assert(idx >= 0 && idx < 32, "level table");
+    for (int j = 0; j < 6; ++j) c.sel[j] = (unsigned)__builtin_amdgcn_sbfe(lane, j, 1);
+    c.a31 = (lane ^ 31) << 2;
+    c.a63 = (lane ^ 63) << 2;
+    return c;
+}
+
+constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v / 2); }
+
+// compare-exchange with the element STRIDE lanes away (STRIDE < 64), smaller one to the lower lane
+template <int R, int STRIDE>
+__device__ __forceinline__ void fast_stride(FastK<R>& t, const SortLanes& c) {
+    const unsigned sel = c.sel[ilog2(STRIDE)];
 #pragma unroll
-        for (int r = 0; r < R; ++r) {
-            // 0 -> min, ~0 -> max.  volatile: the compiler would otherwise hoist all 21 extractions out of the query
-            // loop and hold them in 21 VGPRs (an occupancy step) to save one instruction per level
-            unsigned sel;
-            asm volatile("v_bfe_i32 %0, %1, %2, 1" : "=v"(sel) : "v"(dir[r]), "n"(idx));
-            if constexpr (STRIDE == 16) {
-                // after the swap the two results hold {own, partner} in an order that depends on the lane; as a
-                // set that is all a compare-exchange needs
-                const auto p = __builtin_amdgcn_permlane16_swap(t.e[r], t.e[r], false, false);
-                t.e[r] = umed3(p[0], p[1], sel);
-            } else if constexpr (STRIDE == 32) {
-                const auto p = __builtin_amdgcn_permlane32_swap(t.e[r], t.e[r], false, false);
-                t.e[r] = umed3(p[0], p[1], sel);
-            } else {
-                const unsigned pk = (unsigned)lane_xor<STRIDE>((int)t.e[r]);
-                t.e[r] = umed3(t.e[r], pk, sel);
-            }
+    for (int r = 0; r < R; ++r) {
+        if constexpr (STRIDE == 16) {
+            const auto p = __builtin_amdgcn_permlane16_swap(t.e[r], t.e[r], false, false);
+            t.e[r] = umed3(p[0], p[1], sel);
+        } else if constexpr (STRIDE == 32) {
+            const auto p = __builtin_amdgcn_permlane32_swap(t.e[r], t.e[r], false, false);
+            t.e[r] = umed3(p[0], p[1], sel);
+        } else {
+            t.e[r] = umed3(t.e[r], (unsigned)lane_xor<STRIDE>((int)t.e[r]), sel);
         }
     }
 }
 
-template <int R, int SIZE, int STRIDE>
-__device__ __forceinline__ void fast_strides(FastK<R>& t, const unsigned (&dir)[R]) {
-    fast_level<R, SIZE, STRIDE>(t, dir);
-    if constexpr (STRIDE > 1) fast_strides<R, SIZE, STRIDE / 2>(t, dir);
+// first step of a merge of SIZE elements: element i against element i ^ (SIZE - 1)
+template <int R, int SIZE>
+__device__ __forceinline__ void fast_flip(FastK<R>& t, const SortLanes& c) {
+    if constexpr (SIZE <= 64) {
+        const unsigned sel = c.sel[ilog2(SIZE) - 1];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            unsigned pk;
+            if constexpr (SIZE == 2) pk = (unsigned)__builtin_amdgcn_mov_dpp((int)t.e[r], 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+            else if constexpr (SIZE == 4) pk = (unsigned)__builtin_amdgcn_mov_dpp((int)t.e[r], 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+            else if constexpr (SIZE == 8) pk = (unsigned)__builtin_amdgcn_mov_dpp((int)t.e[r], 0x141, 0xF, 0xF, true);  // row_half_mirror
+            else if constexpr (SIZE == 16) pk = (unsigned)__builtin_amdgcn_mov_dpp((int)t.e[r], 0x140, 0xF, 0xF, true); // row_mirror
+            else if constexpr (SIZE == 32) pk = (unsigned)__builtin_amdgcn_ds_bpermute(c.a31, (int)t.e[r]);
+            else pk = (unsigned)__builtin_amdgcn_ds_bpermute(c.a63, (int)t.e[r]);
+            t.e[r] = umed3(t.e[r], pk, sel);
+        }
+    } else {
+        static_assert(SIZE == 128 && R == 2, "two registers per lane at most");
+        const unsigned lo_rev = (unsigned)__builtin_amdgcn_ds_bpermute(c.a63, (int)t.e[0]);
+        const unsigned hi_rev = (unsigned)__builtin_amdgcn_ds_bpermute(c.a63, (int)t.e[1]);
+        t.e[0] = min(t.e[0], hi_rev);
+        t.e[1] = max(t.e[1], lo_rev);
+    }
 }
 
-// ascending sort of 64 R elements, starting from sorted runs of SIZE / 2
+template <int R, int STRIDE>
+__device__ __forceinline__ void fast_strides(FastK<R>& t, const SortLanes& c) {
+    if constexpr (STRIDE >= 1) {
+        fast_stride<R, STRIDE>(t, c);
+        fast_strides<R, STRIDE / 2>(t, c);
+    }
+}
+
+// ascending sort of 64 R elements (element index = lane + 64 * register), starting from sorted runs of SIZE / 2
 template <int R, int SIZE>
-__device__ __forceinline__ void fast_sort_from(FastK<R>& t, const unsigned (&dir)[R]) {
-    fast_strides<R, SIZE, SIZE / 2>(t, dir);
-    if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2>(t, dir);
+__device__ __forceinline__ void fast_sort_from(FastK<R>& t, const SortLanes& c) {
+    fast_flip<R, SIZE>(t, c);
+    fast_strides<R, SIZE / 4>(t, c);
+    if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2>(t, c);
 }
 
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
@@ -602,9 +603,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     const int lane = lane_id();
     const int64_t item = (int64_t)blockIdx.x * kFastWaves<R> + w;
     if (item >= n_items) return;
-    unsigned sort_dir[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) sort_dir[r] = kSortSel.v[r][lane];
+    const SortLanes sort_dir = make_sort_lanes();
 
     const pct_grid g = a.g;
     const int* __restrict__ cs = a.cell_start;
