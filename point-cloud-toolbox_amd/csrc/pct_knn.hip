@@ -590,9 +590,14 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
 #define PCT_STAGE_CAP2 768
 #endif
     constexpr int CAP = R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
-    constexpr int SLOT_BITS = R == 1 ? 9 : 10;
+    // low bits of a network element: the staged slot of the candidate, or -- pre-selection -- its place in the
+    // compacted list of survivors (6 / 7 bits; the slot is looked up in that list afterwards), which leaves three
+    // more bits for the key and cuts key collisions eightfold
+    constexpr int SLOT_BITS = PRE ? (R == 1 ? 6 : 7) : (R == 1 ? 9 : 10);
     constexpr int KEY_BITS = 32 - SLOT_BITS;
-    static_assert(CAP <= (1 << SLOT_BITS), "slot field too narrow");
+    constexpr int CAP_POW2 = 1024;          // slots < CAP <= 1024: masks a garbage list entry read for a padding element
+    static_assert(CAP <= CAP_POW2, "staging capacity");
+    static_assert(PRE || CAP <= (1 << SLOT_BITS), "slot field too narrow");
     __shared__ float s_cx[kFastWaves<R>][CAP];        // staged stencil, structure of arrays:
     __shared__ float s_cy[kFastWaves<R>][CAP];        // 12 B per candidate
     __shared__ float s_cz[kFastWaves<R>][CAP];
@@ -851,7 +856,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                         const int j = (int)pend[i];
                         const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
                         const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        if (!EPS || d2 < eps2) e = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)j;
+                        if (!EPS || d2 < eps2) e = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
                     }
                     best.e[r] = e;
                 }
@@ -986,7 +991,8 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             const int i = lane + 64 * r;
             const unsigned e = best.e[r];
             const bool real = e != kPadElem;
-            const int j = (int)(e & ((1u << SLOT_BITS) - 1u));       // staged slot (anything for padding)
+            int j = (int)(e & ((1u << SLOT_BITS) - 1u));             // staged slot (anything for padding)
+            if constexpr (PRE) j = (int)pend[j] & (CAP_POW2 - 1);        // ... via the survivors' list (still intact)
             // sorted position of slot j = j + offset of its run.  The cross-lane reads need every lane active:
             // they stay outside the divergent part.
             unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
