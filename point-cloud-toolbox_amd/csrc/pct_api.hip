@@ -392,6 +392,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
     ctx->fit_rows = rows;
+    ctx->fit_row_order = false;
     ctx->fit_valid = true;
     ctx->knn_valid = false;   // results are row-aligned now, not cloud-aligned
     return PCT_OK;
@@ -405,6 +406,19 @@ int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end, float* coefs, float* K
         return pct_fail(ctx, PCT_ERR_INVALID, "rows [%lld,%lld) outside the fitted range", (long long)begin, (long long)end);
     const int64_t rows = end - begin, off = begin - base;
     if (rows == 0) return PCT_OK;
+    if (ctx->fit_row_order) {          // results live in table-row order: gather the requested public rows first
+        float *d_c = nullptr, *d_s = nullptr;
+        if (coefs) { PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)rows * 6 * sizeof(float))); d_c = (float*)ctx->stage_a.p; }
+        PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)rows * 3 * sizeof(float)));
+        d_s = (float*)ctx->stage_b.p;
+        PCT_TRY(pct_launch_gather_fit(ctx, off, rows, d_c, K ? d_s : nullptr, H ? d_s + rows : nullptr, H2 ? d_s + 2 * rows : nullptr));
+        if (coefs) PCT_HIP(ctx, hipMemcpyAsync(coefs, d_c, (size_t)rows * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (K) PCT_HIP(ctx, hipMemcpyAsync(K, d_s, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (H) PCT_HIP(ctx, hipMemcpyAsync(H, d_s + rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (H2) PCT_HIP(ctx, hipMemcpyAsync(H2, d_s + 2 * rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return PCT_OK;
+    }
     if (coefs) PCT_HIP(ctx, hipMemcpyAsync(coefs, (float*)ctx->coefs.p + off * 6, (size_t)rows * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (K) PCT_HIP(ctx, hipMemcpyAsync(K, (float*)ctx->K.p + off, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
     if (H) PCT_HIP(ctx, hipMemcpyAsync(H, (float*)ctx->H.p + off, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));

@@ -481,6 +481,24 @@ __global__ __launch_bounds__(256) void k_prefix_rows(const int* __restrict__ sam
     if (threadIdx.x == 0) { cnt[row] = n + 1; row_query[row] = q; }
 }
 
+// public rows [first, first + rows) of the owned range out of row-ordered results
+__global__ __launch_bounds__(256) void k_gather_fit(const int* __restrict__ row_of, int64_t first, int64_t rows,
+                                                    const float* __restrict__ coefs, const float* __restrict__ K,
+                                                    const float* __restrict__ H, const float* __restrict__ H2,
+                                                    float* __restrict__ o_coefs, float* __restrict__ o_K,
+                                                    float* __restrict__ o_H, float* __restrict__ o_H2) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    const int64_t r = row_of[first + i];
+    if (o_coefs) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j) o_coefs[i * 6 + j] = coefs[r * 6 + j];
+    }
+    if (o_K) o_K[i] = K[r];
+    if (o_H) o_H[i] = H[r];
+    if (o_H2) o_H2[i] = H2[r];
+}
+
 int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     FitArgs a = a0;
     a.kp = a.k | 1;
@@ -516,7 +534,11 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     a.rows = nq;
     a.k = ctx->k;
     a.pitch = ctx->nbr_pitch;
-    a.out_by_row = 0;
+    // Grid sweep: results stay in TABLE-ROW (cell) order -- a wave's 64 rows are consecutive, so the stores
+    // coalesce; written in public order they were 36 B scattered per point and cost 4x the bytes at the HBM
+    // (WRITE_SIZE 145 MB vs 36 MB).  pct_get_fit gathers public rows on request (pct_launch_gather_fit).
+    a.out_by_row = sorted ? 1 : 0;
+    ctx->fit_row_order = sorted;
     a.out_base = ctx->q_begin;
     a.q_begin = (int)ctx->q_begin;
     a.q_end = (int)ctx->q_end;
@@ -525,6 +547,14 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     a.H = (float*)ctx->H.p;
     a.H2 = (float*)ctx->H2.p;
     return launch(ctx, a, ctx->has_f64);
+}
+
+int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
+    hipLaunchKernelGGL(k_gather_fit, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->row_of.p,
+                       first, rows, (const float*)ctx->coefs.p, (const float*)ctx->K.p, (const float*)ctx->H.p,
+                       (const float*)ctx->H2.p, d_coefs, d_K, d_H, d_H2);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
 }
 
 // fit from explicit neighbour rows, outputs row-aligned.  sorted_space: ids refer to the cell-sorted arrays.

@@ -98,6 +98,7 @@ struct pct_ctx {
     pct_buf K, H, H2;   // float (n)
     int64_t fit_rows = 0;
     bool fit_valid = false;
+    bool fit_row_order = false;    // results are in neighbour-table row order (grid sweep), not public order
 
     // staging for downloads / host-index fits
     pct_buf stage_a, stage_b, stage_c, stage_d;
@@ -138,6 +139,7 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
                         float* d_coefs, float* d_K, float* d_H, float* d_H2, bool sorted_space, bool minnorm_pass);
 int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samples, int n_lo, int n_hi, int* d_table,
                            int pitch, int* d_cnt, int64_t* d_row_query);
+int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);
