@@ -570,7 +570,10 @@ __device__ __forceinline__ void fast_sort_from(FastK<R>& t, const SortLanes& c) 
 
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
 // R = 1: 6 blocks x 4 waves x 6.25 KiB, R = 2: 4 blocks x 4 waves x 9.5 KiB)
-template <int R> constexpr int kFastWaves = 4;
+#ifndef PCT_FAST_WAVES
+#define PCT_FAST_WAVES 4
+#endif
+template <int R> constexpr int kFastWaves = PCT_FAST_WAVES;
 
 // EPS = the hybrid eps-ball query is on (candidates beyond eps do not count); without it every staged slot is a
 // candidate and the per-batch eps compares and candidate counts drop out.
