@@ -568,6 +568,14 @@ __device__ __forceinline__ void fast_sort_from(FastK<R>& t, const SortLanes& c) 
     if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2>(t, c);
 }
 
+// NSETS independent ascending sorts of 64 elements each (one register per set), level by level side by side
+template <int NSETS, int SIZE>
+__device__ __forceinline__ void fast_sort_sets(FastK<NSETS>& t, const SortLanes& c) {
+    fast_flip<NSETS, SIZE>(t, c);
+    fast_strides<NSETS, SIZE / 4>(t, c);
+    if constexpr (SIZE < 64) fast_sort_sets<NSETS, SIZE * 2>(t, c);
+}
+
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
 // R = 1: 6 blocks x 4 waves x 6.25 KiB, R = 2: 4 blocks x 4 waves x 9.5 KiB)
 #ifndef PCT_FAST_WAVES
@@ -585,7 +593,9 @@ template <int R> constexpr int kFastWaves = PCT_FAST_WAVES;
 // exact squared distance >= T (1 - 2^-20): the query is accepted only if its (k+1)-th exact key lies below that.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-template <int R, bool EPS, bool PRE>
+// PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
+// basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
+template <int R, bool EPS, bool PRE, bool PAIR = false>
 __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
@@ -605,6 +615,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     __shared__ float s_cy[kFastWaves<R>][CAP];        // 12 B per candidate
     __shared__ float s_cz[kFastWaves<R>][CAP];
     __shared__ unsigned s_pend[kFastWaves<R>][64 * R];
+    __shared__ unsigned s_pend2[kFastWaves<R>][PAIR ? 64 * R : 1];    // list of the second query of a pair
     __shared__ int s_offc[kFastWaves<R>][16];          // sorted position - flat slot, per non-empty run
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -758,6 +769,207 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     // test follows on the survivors
     const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
 
+    if constexpr (PRE && PAIR) {
+        static_assert(R == 1, "pairs: one register per list");
+        unsigned* pend_b = s_pend2[w];
+        const auto push_redo = [&](int row) {
+            if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+            ++n_redo;
+        };
+        for (int qi = 0; qi < nq; qi += 2) {
+            const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
+            const int qj = live_b ? qi + 1 : qi;
+            const int row_a = row0 + qi, row_b = row0 + qj;
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+            const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
+            const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
+            const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
+            // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
+            float ap_a[NB], ap_b[NB];
+#pragma unroll
+            for (int p2 = 0; p2 < NB / 2; ++p2) {
+                ap_a[2 * p2] = ap_a[2 * p2 + 1] = INFINITY;
+                ap_b[2 * p2] = ap_b[2 * p2 + 1] = INFINITY;
+                if (p2 * 128 < m) {
+                    const int sa = p2 * 128 + lane, sb = sa + 64;
+                    const float2v vx = {cand_x[sa], cand_x[sb]}, vy = {cand_y[sa], cand_y[sb]}, vz = {cand_z[sa], cand_z[sb]};
+                    {
+                        const float2v dx = vx - ax, dy = vy - ay, dz = vz - az;
+                        float2v d = dx * dx;
+                        d = __builtin_elementwise_fma(dy, dy, d);
+                        d = __builtin_elementwise_fma(dz, dz, d);
+                        ap_a[2 * p2] = d.x;
+                        ap_a[2 * p2 + 1] = d.y;
+                    }
+                    {
+                        const float2v dx = vx - bx, dy = vy - by, dz = vz - bz;
+                        float2v d = dx * dx;
+                        d = __builtin_elementwise_fma(dy, dy, d);
+                        d = __builtin_elementwise_fma(dz, dz, d);
+                        ap_b[2 * p2] = d.x;
+                        ap_b[2 * p2 + 1] = d.y;
+                    }
+                    n_step += 4;
+                }
+            }
+            // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball ----------------------
+            float T_a = EPS ? eps2a : INFINITY, T_b = T_a;
+            int tot_a = m, tot_b = m;
+            if constexpr (EPS) {
+                tot_a = tot_b = 0;
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    if ((b & ~1) * 64 < m) {
+                        tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < T_a));
+                        tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < T_b));
+                    }
+            }
+            int cnt_a = tot_a, cnt_b = tot_b;
+            bool ok_a = true, ok_b = live_b;              // still on the fast path
+            unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;
+            const bool need_a = tot_a > LIST, need_b = live_b && tot_b > LIST;
+            if (need_a || need_b) {
+                const float target = 0.5f * (float)(k + 1 + LIST);
+                float t0 = t_prev_f > 0.f ? t_prev_f : cell2f;
+                if (!(t0 < T_a)) t0 = 0.5f * T_a;
+                float lo_a = 0.f, hi_a = T_a, t_a = t0, lo_b = 0.f, hi_b = T_b, t_b = t0;
+                bool go_a = need_a, go_b = need_b, found_a = !need_a, found_b = !need_b;
+#pragma unroll 1
+                for (int trial = 0; trial < 16 && (go_a || go_b); ++trial) {
+                    int c_a = 0, c_b = 0;
+#pragma unroll
+                    for (int b = 0; b < NB; ++b)
+                        if ((b & ~1) * 64 < m) {
+                            c_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < t_a));
+                            c_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < t_b));
+                        }
+                    if (go_a) {
+                        if (c_a >= k + 1 && c_a <= LIST) { T_a = t_a; cnt_a = c_a; found_a = true; go_a = false; }
+                        else {
+                            if (c_a < k + 1) lo_a = t_a; else hi_a = t_a;
+                            float nt = c_a > 0 ? t_a * target * __builtin_amdgcn_rcpf((float)c_a) : 4.f * t_a;
+                            if (!(nt > lo_a && nt < hi_a)) nt = hi_a < INFINITY ? 0.5f * (lo_a + hi_a) : 2.f * lo_a;
+                            nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
+                            if (!(nt > lo_a && nt < hi_a)) go_a = false; else t_a = nt;   // no float left between
+                        }
+                    }
+                    if (go_b) {
+                        if (c_b >= k + 1 && c_b <= LIST) { T_b = t_b; cnt_b = c_b; found_b = true; go_b = false; }
+                        else {
+                            if (c_b < k + 1) lo_b = t_b; else hi_b = t_b;
+                            float nt = c_b > 0 ? t_b * target * __builtin_amdgcn_rcpf((float)c_b) : 4.f * t_b;
+                            if (!(nt > lo_b && nt < hi_b)) nt = hi_b < INFINITY ? 0.5f * (lo_b + hi_b) : 2.f * lo_b;
+                            nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
+                            if (!(nt > lo_b && nt < hi_b)) go_b = false; else t_b = nt;
+                        }
+                    }
+                }
+                if (need_a) {
+                    ok_a = found_a && T_a >= 1e-30f;
+                    if (ok_a) { t_prev_f = T_a; bkey_a = (unsigned)fmin((double)T_a * (1.0 - 0x1p-20) * scale, 4294967294.0); }
+                }
+                if (need_b) {
+                    ok_b = ok_b && found_b && T_b >= 1e-30f;
+                    if (ok_b) { t_prev_f = T_b; bkey_b = (unsigned)fmin((double)T_b * (1.0 - 0x1p-20) * scale, 4294967294.0); }
+                }
+                if (!ok_a) { push_redo(row_a); T_a = 0.f; cnt_a = 0; }           // nothing passes, nothing is stored
+                if (!ok_b) { if (live_b) push_redo(row_b); T_b = 0.f; cnt_b = 0; }
+                if (!ok_a && !ok_b) continue;
+            }
+            if (!live_b) { T_b = 0.f; cnt_b = 0; }
+            // ---- compact the slots of the survivors of both queries, then exact keys for them only ------------------
+            FastK<2> both;
+            {
+                int base_a = 0, base_b = 0;
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    if ((b & ~1) * 64 < m) {
+                        const bool pa = ap_a[b] < T_a, pb = ap_b[b] < T_b;
+                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
+                        if (pa) pend[base_a + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0))] = (unsigned)(b * 64 + lane);
+                        if (pb) pend_b[base_b + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0))] = (unsigned)(b * 64 + lane);
+                        base_a += (int)__popcll(ma);
+                        base_b += (int)__popcll(mb);
+                    }
+                }
+                wave_lds_sync();
+                const double qax = (double)ax, qay = (double)ay, qaz = (double)az, qbx = (double)bx, qby = (double)by, qbz = (double)bz;
+                unsigned e_a = kPadElem, e_b = kPadElem;
+                if (lane < cnt_a) {
+                    const int j = (int)pend[lane];
+                    const double dx = (double)cand_x[j] - qax, dy = (double)cand_y[j] - qay, dz = (double)cand_z[j] - qaz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+                }
+                if (lane < cnt_b) {
+                    const int j = (int)pend_b[lane];
+                    const double dx = (double)cand_x[j] - qbx, dy = (double)cand_y[j] - qby, dz = (double)cand_z[j] - qbz;
+                    const double d2 = (dx * dx + dy * dy) + dz * dz;
+                    if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+                }
+                both.e[0] = e_a;
+                both.e[1] = e_b;
+                wave_lds_sync();
+                fast_sort_sets<2, 2>(both, sort_dir);
+                n_flush += 2;
+            }
+            // ---- proof obligations per query (see the single-query path below) -----------------------------------------
+            bool amb_a = false, amb_b = false;
+            {
+                const unsigned tau_a = (unsigned)__builtin_amdgcn_readlane((int)both.e[0], k);
+                const unsigned tau_b = (unsigned)__builtin_amdgcn_readlane((int)both.e[1], k);
+                const unsigned gk_a = min((unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi), bkey_a);
+                const unsigned gk_b = min((unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj), bkey_b);
+                const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
+                amb_a |= min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key) > gk_a;
+                amb_b |= min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key) > gk_b;
+                amb_a |= tau_a != kPadElem && tk_a >= key_max - 1u;
+                amb_b |= tau_b != kPadElem && tk_b >= key_max - 1u;
+                unsigned up_a = __shfl_down(both.e[0], 1), up_b = __shfl_down(both.e[1], 1);
+                if (lane == 63) { up_a = kPadElem; up_b = kPadElem; }
+                amb_a |= lane <= k && both.e[0] != kPadElem && up_a != kPadElem && ((both.e[0] ^ up_a) >> SLOT_BITS) == 0u;
+                amb_b |= lane <= k && both.e[1] != kPadElem && up_b != kPadElem && ((both.e[1] ^ up_b) >> SLOT_BITS) == 0u;
+            }
+            if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a); ok_a = false; }
+            if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b); ok_b = false; }
+            // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
+#pragma unroll
+            for (int set = 0; set < 2; ++set) {
+                const unsigned e = both.e[set];
+                const bool real = e != kPadElem;
+                const unsigned* lst = set == 0 ? pend : pend_b;
+                const int j = (int)lst[e & ((1u << SLOT_BITS) - 1u)] & (CAP_POW2 - 1);
+                const unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+                const unsigned t = (code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u;
+                const int pos_real = j + offc[t];
+                const bool ok = set == 0 ? ok_a : ok_b;
+                const int row = set == 0 ? row_a : row_b;
+                if (ok) {
+                    int found = 0;
+                    if (lane >= 1 && lane <= k) {
+                        int pos = -1;
+                        float dist = INFINITY;
+                        if (real) {
+                            const double qx = (double)(set == 0 ? ax : bx), qy = (double)(set == 0 ? ay : by), qz = (double)(set == 0 ? az : bz);
+                            const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
+                            dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
+                            pos = pos_real;
+                        }
+                        a.nbr_pos[(int64_t)row * a.pitch + (lane - 1)] = pos;
+                        a.nbr_dist[(int64_t)row * a.pitch + (lane - 1)] = dist;
+                        found += real;
+                    }
+                    if (a.nbr_cnt) {
+                        for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
+                        if (lane == 0) a.nbr_cnt[row] = found;
+                    }
+                }
+            }
+        }
+    } else
     for (int qi = 0; qi < nq; ++qi) {
         const int row = row0 + qi;
         double qx, qy, qz;
@@ -1180,7 +1392,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
         const bool e = eps > 0, pre = !ctx->has_f64, r1 = k + 1 <= 64;
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        if (r1 && !e && pre) PCT_FAST(1, false, true, grid1, block1);
+        static const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;          // tuning aid
+#define PCT_FAST_PAIR(E_) \
+    hipLaunchKernelGGL((k_knn_fast<1, E_, true, true>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (r1 && !e && pre && !no_pair) PCT_FAST_PAIR(false);
+        else if (r1 && e && pre && !no_pair) PCT_FAST_PAIR(true);
+        else if (r1 && !e && pre) PCT_FAST(1, false, true, grid1, block1);
         else if (r1 && e && pre) PCT_FAST(1, true, true, grid1, block1);
         else if (r1 && !e) PCT_FAST(1, false, false, grid1, block1);
         else if (r1) PCT_FAST(1, true, false, grid1, block1);
@@ -1189,6 +1406,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
         else if (!e) PCT_FAST(2, false, false, grid2, block2);
         else PCT_FAST(2, true, false, grid2, block2);
 #undef PCT_FAST
+#undef PCT_FAST_PAIR
         PCT_HIP(ctx, hipGetLastError());
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
