@@ -34,7 +34,9 @@ enum pct_knn_algo {
     PCT_KNN_AUTO = 0,
     PCT_KNN_BRUTE = 1,        /* exhaustive wave-per-query sweep                        */
     PCT_KNN_GRID = 2,         /* uniform cell list, LDS-staged 27-cell stencil          */
-    PCT_KNN_GRID_EXACT = 3    /* same cell list, every query through the exact sweep    */
+    PCT_KNN_GRID_EXACT = 3,   /* same cell list, every query through the exact sweep    */
+    PCT_KNN_GRID_LEVELS = 4   /* chain of cell lists, each sized for the queries the previous
+                                 one could not answer (clouds of very uneven density)   */
 };
 
 /* Per-stage device times of the most recent call, hipEvent milliseconds. */
@@ -60,7 +62,7 @@ typedef struct pct_timings {
                                  near the owned range                                    */
     int32_t limit_retries;    /* 1 = the sweep was repeated with every point because a query reached past
                                  the part kept                                            */
-    int32_t reserved_;
+    int32_t levels;           /* passes of the density-adaptive sweep (0 = not used)       */
     double occupancy;         /* mean number of points sharing a point's cell (the cell-size search steers on it) */
 } pct_timings;
 

@@ -23,7 +23,7 @@ PCT_ERR_K_TOO_LARGE = 5
 PCT_ERR_OOM = 6
 PCT_ERR_NO_NEIGHBORS = 7
 
-KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT = 0, 1, 2, 3
+KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT, KNN_GRID_LEVELS = 0, 1, 2, 3, 4
 
 
 class Timings(C.Structure):
@@ -35,7 +35,7 @@ class Timings(C.Structure):
         ("ring_fallbacks", C.c_int64), ("lds_overflows", C.c_int64),
         ("flushes", C.c_int64), ("candidate_steps", C.c_int64), ("redone_queries", C.c_int64),
         ("cell_size", C.c_double),
-        ("grid_points", C.c_int64), ("limit_retries", C.c_int32), ("reserved_", C.c_int32),
+        ("grid_points", C.c_int64), ("limit_retries", C.c_int32), ("levels", C.c_int32),
         ("occupancy", C.c_double),
     ]
 

@@ -92,7 +92,7 @@ void pct_destroy(pct_ctx* ctx) {
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
                       &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
-                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d};
+                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt};
     for (pct_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
@@ -207,11 +207,26 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
     if (!(eps >= 0) || isinf(eps)) eps = 0;
     if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
-    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT) return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
+    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS)
+        return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
+    // (ctx->uneven records that the last plain grid sweep left > 5 % of the queries to the exact kernel; the chained
+    // sweep is opt-in all the same: it wins on extreme density ranges only)
     ctx->knn_valid = ctx->fit_valid = false;
     ctx->k = k;
     ctx->eps = eps;
     PCT_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+    ctx->tm.levels = 0;
+    if (algo == PCT_KNN_GRID_LEVELS) {
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        PCT_TRY(pct_knn_levels(ctx, k, eps));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        ctx->tm.knn_launches = ctx->tm.levels;
+        ctx->knn_valid = true;
+        ctx->last_levels = true;
+        return PCT_OK;
+    }
+    ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
     if (grid) {
         PCT_TRY(pct_build_grid(ctx, k, eps));
@@ -236,7 +251,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
 
 static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
     unsigned long long* c = (unsigned long long*)(ctx->pin + 192);       // pinned: a plain DMA, no staging
-    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 6 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));   // [7] low word: rows on the redo list
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.ring_fallbacks = (int64_t)c[0];
     ctx->tm.lds_overflows = (int64_t)c[1];
@@ -248,6 +263,11 @@ static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
     ctx->tm.knn_fast_ms = ctx->knn_sorted_space ? ev_ms(ctx, 3, 7) : 0.f;
     // a sharded handle that left far points out of its grid met a query those points could matter to
     *beyond_limits = ctx->knn_sorted_space && ctx->culled && c[5] > 0;
+    // uneven density: remember it for the next sweep on this handle (and forget it when a chain needed one pass)
+    const int64_t owned = ctx->q_end - ctx->q_begin;
+    const int64_t redone = (int64_t)(unsigned)(c[7] & 0xFFFFFFFFull);
+    if (ctx->knn_sorted_space && !ctx->last_levels) ctx->uneven = redone * 20 > owned && owned >= 65536;
+    else if (ctx->last_levels && ctx->tm.levels <= 1) ctx->uneven = false;
     ctx->tm.limit_retries = ctx->retries;
     return PCT_OK;
 }

@@ -346,20 +346,41 @@ __device__ __forceinline__ int cell_coord(double x, double o, double inv, int n)
 // integer atomic returns is the point's arrival rank in its class -- the
 // scatter then needs no second atomic pass.
 __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4, int64_t n, pct_grid g, int q_begin, int q_end,
+                                                 const float* __restrict__ own_want, float own_lo, float own_hi, int skip_outside,
                                                  int* __restrict__ cell_of, int* __restrict__ rank_of,
                                                  int* __restrict__ cell_own, int* __restrict__ cell_oth) {
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     float4 p = pts4[i];
+    if (skip_outside) {
+        // fast level pass over a sub-box: a point outside the box would only be clamped into a boundary cell that no
+        // owned stencil touches -- and a million of them into the same few cells serialise the atomics.  Leave it out.
+        const double fx = floor(((double)p.x - g.ox) * g.inv_cell), fy = floor(((double)p.y - g.oy) * g.inv_cell),
+                     fz = floor(((double)p.z - g.oz) * g.inv_cell);
+        if (fx < 0 || fx >= g.nx || fy < 0 || fy >= g.ny || fz < 0 || fz >= g.nz) {
+            cell_of[i] = -1;
+            return;
+        }
+    }
     int cx = cell_coord((double)p.x, g.ox, g.inv_cell, g.nx);
     int cy = cell_coord((double)p.y, g.oy, g.inv_cell, g.ny);
     int cz = cell_coord((double)p.z, g.oz, g.inv_cell, g.nz);
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_of[i] = c;
-    if (i >= q_begin && i < q_end)
+    // level passes (pct_levels.hip) own the still unanswered points whose wanted cell edge (log2) lies in a band
+    const bool owned = own_want ? (own_want[i] >= own_lo && own_want[i] < own_hi) : (i >= q_begin && i < q_end);
+    if (owned) {
         rank_of[i] = atomicAdd(&cell_own[c], 1);
-    else
+    } else {
+        // fast level pass: a cell that already holds far more candidates than the sweep can stage overflows every
+        // stencil it is part of (those queries go to another pass whatever happens), so further candidates in it are
+        // dead weight -- and a hundred thousand of them on one counter serialise (~88 atomics/us per address)
+        if (skip_outside && __builtin_nontemporal_load(&cell_oth[c]) > 2048) {
+            cell_of[i] = -1;
+            return;
+        }
         rank_of[i] = atomicAdd(&cell_oth[c], 1) | (int)0x80000000;
+    }
 }
 
 // ---- triple exclusive scan over the cells ---------------------------------
@@ -378,8 +399,8 @@ __device__ __forceinline__ int4 cell_counts(const int* __restrict__ own, const i
     return make_int4(t, (o + items_q - 1) / items_q, o, 0);
 }
 
-// first pass: per-tile sums; also accumulates sum_c count_c^2 (= sum over points of the population of
-// their own cell), the statistic the cell-size loop steers on
+// first pass: per-tile sums; also accumulates sum_c owned_c * count_c (= sum over the owned points of the
+// population of their own cell), the statistic the cell-size loop steers on
 __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ own, const int* __restrict__ oth, int64_t ncell, int items_q,
                                                       int4* __restrict__ tmp, unsigned long long* __restrict__ sq_part) {
     __shared__ int4 sh[kBlock / 64];
@@ -390,7 +411,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ ow
     for (int j = 0; j < kScanItems; ++j) {
         const int4 x = cell_counts(own, oth, base + j, ncell, items_q);
         v = add3(v, x);
-        sq += (unsigned long long)x.x * (unsigned)x.x;
+        sq += (unsigned long long)x.z * (unsigned)x.x;       // owned points x population of their cell
     }
     for (int o = 32; o > 0; o >>= 1) {
         v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o);
@@ -498,6 +519,7 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ p
     int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int c = cell_of[i];
+    if (c < 0) return;                  // left out of this pass's cell list
     const int r = rank_of[i];
     int pos, row;
     if (r >= 0) {
@@ -692,22 +714,33 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // trips to the exact sweep; the LDS staging capacity caps the large side
     const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 32 ? 0.65 : k + 1 <= 64 ? 0.55 : 0.45);
     const double target = factor * (k + 1);
-    const int64_t cell_cap = (int64_t)1 << 27;
-    const int64_t n_owned = ctx->q_end - ctx->q_begin;
-    const bool sharded = ctx->q_begin > 0 || ctx->q_end < ctx->n;        // some points are candidates only
+    // (the first pass of a chained sweep only has to be roughly right: the later passes adapt)
+    const int64_t cell_cap = (int64_t)1 << (ctx->level_mode ? 24 : 27);
+    const float* own_flag = (const float*)ctx->own_flag;   // level passes: ownership by wanted-edge band
+    const int64_t n_owned = own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
+    const bool sharded = own_flag || ctx->q_begin > 0 || ctx->q_end < ctx->n;   // some points are candidates only
 
     float bbox[6];
     PackRed red;
     Box3 kept_box = {};
-    const bool try_cull = sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !getenv("PCT_NO_CULL");
+    const bool try_cull = !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !getenv("PCT_NO_CULL");
     ctx->tm.grid_iters = 0;
     if (try_cull)
         PCT_TRY(pack_near_owned(ctx, target, bbox, &red, &kept_box));
     else
         PCT_TRY(pack_all(ctx, bbox, &red));
     PCT_TRY(trim_box(ctx, red, bbox));
+    const bool sub_box = ctx->level_edge > 0 && ctx->level_box_valid;
+    if (sub_box) {
+        // a fast level pass only needs cells around its owned points: box = their bbox + 2.5 edges (their stencils
+        // end one cell short of the boundary cells, into which every other point is clamped)
+        for (int a = 0; a < 3; ++a) {       // (not intersected with the trimmed box: every owned point must be inside)
+            bbox[a] = ctx->level_box[a] - (float)(2.5 * ctx->level_edge);
+            bbox[3 + a] = ctx->level_box[3 + a] + (float)(2.5 * ctx->level_edge);
+        }
+    }
     const int64_t n = ctx->n_grid;                                        // points the grid holds
-    const int g_begin = (int)ctx->g_begin, g_end = (int)(ctx->g_begin + n_owned);
+    const int g_begin = own_flag ? 0 : (int)ctx->g_begin, g_end = own_flag ? 0 : (int)(ctx->g_begin + n_owned);
 
     double ex = (double)bbox[3] - bbox[0], ey = (double)bbox[4] - bbox[1], ez = (double)bbox[5] - bbox[2];
     double emax = fmax(ex, fmax(ey, ez));
@@ -720,7 +753,10 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // Warm start: a handle that sees a stream of similar clouds (same scanner, same shard of the same job) reuses
     // the edge the last build converged to, rescaled by the first-guess ratio, and so normally needs one pass.
     const double first_guess_raw = a;
-    if (ctx->hint_edge > 0 && ctx->hint_guess > 0) {
+    const bool level_pass = ctx->level_edge > 0;          // a later level of the density-adaptive sweep: edge given
+    if (level_pass) {
+        a = ctx->level_edge;
+    } else if (ctx->hint_edge > 0 && ctx->hint_guess > 0) {
         const double r = first_guess_raw / ctx->hint_guess * sqrt(ctx->hint_target / target);   // guess ~ sqrt(target)
         if (r > 0.5 && r < 2.0) a = ctx->hint_edge * r * sqrt(target / ctx->hint_target);
     }
@@ -732,14 +768,17 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
-    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)(n_owned + 1) * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)((own_flag ? n : n_owned) + 1) * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, (size_t)n_owned * sizeof(int)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, (size_t)n * sizeof(double4)));
     int nblk = 0;
     pct_grid g = {};
     double a_prev = 0, m_prev = 0;
     int iters = 0;
-    const int max_iter = 8;
+    // a level pass takes the edge it is given: its owned set is a mix of densities, and the mean population this
+    // loop steers on would be pulled to the dense minority (pct_levels.hip sizes by the geometric mean instead)
+    const int max_iter = level_pass ? 1 : ctx->level_mode ? 2 : 8;
+    const double win_lo = 0.88, win_hi = 1.12;
     int4 tot = make_int4(0, 0, 0, 0);
     double m_last = 0, d_last = 2.0;
     // Every pass runs the whole build (histogram, scan, scatter) and only then reads back the occupancy statistic
@@ -759,7 +798,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
             PCT_HIP(ctx, hipMemsetAsync(ctx->cell_oth.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
         }
         hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, n, g, g_begin, g_end, (int*)ctx->cell_of.p,
+                           (const float4*)ctx->pts4.p, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
@@ -786,11 +825,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         const unsigned long long s2 = ((const ScanTotals*)(ctx->pin + 128))->sumsq;
         tot = ((const ScanTotals*)(ctx->pin + 128))->tot;
         ++iters;
-        double m = (double)s2 / (double)n;
+        double m = (double)s2 / (double)(n_owned > 0 ? n_owned : 1);
         m_last = m;
         bool eps_bound = eps > 0 && a >= eps;            // cannot grow past eps
         bool capped = g.ncell * 2 > cell_cap && m < target;
-        if ((m >= 0.88 * target && m <= 1.12 * target) || it == max_iter - 1 || (eps_bound && m < target) ||
+        if ((m >= win_lo * target && m <= win_hi * target) || it == max_iter - 1 || (eps_bound && m < target) ||
             capped || (a >= emax && m < target))
             break;
         double d = 2.0;
@@ -818,16 +857,16 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->tm.cell_size = g.cell;
     ctx->tm.grid_points = n;
     ctx->tm.occupancy = m_last;
-    if (m_last > 0) {        // what the heuristic first guess should have been for this cloud
+    if (m_last > 0 && !level_pass) {        // what the heuristic first guess should have been for this cloud
         ctx->hint_edge = g.cell * pow(target / m_last, 1.0 / d_last);
         ctx->hint_guess = first_guess_raw;
         ctx->hint_target = target;
     }
-    if (tot.x != n || tot.z != n_owned)
+    if ((tot.x != n && !sub_box) || tot.x > n || tot.z != n_owned)
         return pct_fail(ctx, PCT_ERR_INVALID, "cell scan totals %d/%d != %lld/%lld", tot.x, tot.z, (long long)n, (long long)n_owned);
     // A uniform cell list cannot resolve every cloud (tight clusters very far apart exhaust the cell budget):
     // refuse when the sweep would degenerate into an all-pairs scan of hours rather than run it.
-    if (m_last > 64.0 * target && m_last * 27.0 * (double)n_owned > 1e12)
+    if (!level_pass && m_last > 64.0 * target && m_last * 27.0 * (double)n_owned > 1e12)
         return pct_fail(ctx, PCT_ERR_INVALID,
                         "the cell list cannot resolve this cloud: a point shares its cell with %.0f others on average at the "
                         "smallest usable cell edge %.3g (%lld cells); thin it out or split it into compact pieces",

@@ -47,6 +47,22 @@ struct pct_ctx {
     bool no_cull = false;          // set after a sweep met a query the kept points cannot answer
     int32_t retries = 0;
     double hint_edge = 0, hint_guess = 0, hint_target = 0;   // warm start of the cell-size search (pct_build_grid)
+    // density-adaptive sweep (pct_levels.hip): the queries one pass could not answer are re-owned by the next
+    // pass, which sizes its cells for THEM
+    const void* own_flag = nullptr; // device float (n): wanted log2 cell edge of every unanswered point (NaN = answered); null = ownership by index range
+    float own_lo = 0, own_hi = 0;   // the pass owns the points with own_lo <= wanted < own_hi
+    float level_box[6] = {0, 0, 0, 0, 0, 0};   // bbox of the owned points of a fast level pass
+    bool level_box_valid = false;
+    int64_t own_count = 0;
+    double level_edge = 0;          // > 0: first cell edge of this pass
+    bool level_mode = false;        // a density-adaptive sweep is in progress (rows answered are recorded in row_done)
+    pct_buf row_done;               // int32 (rows of the pass)
+    pct_buf redo_m;                 // int32, parallel to redo: stencil population of the row's item
+    pct_buf flag_buf;               // float (n): wanted log2 cell edge of every point still unanswered (NaN = answered)
+    pct_buf dens_buf;               // float2 (n): log2 of the largest edge known too small / the smallest known too large
+    pct_buf pub_pos, pub_dist, pub_cnt;   // public-space neighbour table the passes are merged into
+    bool uneven = false;
+    bool last_levels = false;       // the table in place came from pct_knn_levels            // a plain grid sweep of this cloud left > 5 % of the queries to the exact kernel
     bool has_f64 = false;
     double occupancy_factor = 0.0; // 0 = default
     bool collect_stats = false;    // sweep statistics (costly same-address atomics)
@@ -128,8 +144,9 @@ int pct_pack_points(pct_ctx* ctx, float* bbox6);
 int pct_pack_points_f64(pct_ctx* ctx, const double* d_xyz64);
 int pct_build_grid(pct_ctx* ctx, int32_t k, double eps);
 // neighbour sweeps (pct_knn.hip)
-int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only);
+int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, int phase = 0);
 int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
+int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps);     // pct_levels.hip
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);
 // fit (pct_fit.hip)

@@ -54,6 +54,8 @@ struct KnnArgs {
     int* nbr_pos;
     float* nbr_dist;
     int* nbr_cnt;             // nullable
+    int* row_done;            // nullable: set to 1 for every row a kernel has answered (level passes)
+    int* redo_m;              // nullable, parallel to the redo list: candidates the stencil of the row's item held
     int stats;                // collect the counters below (off by default)
     unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries [5] queries beyond the culling limits (always counted)
 };
@@ -447,6 +449,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
         }
         if (a.stats && lane == 0 && it.ring > 1) atomicAdd(&a.counters[0], 1ull);
         sw.store(row, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+        if (a.row_done && lane == 0) a.row_done[row] = 1;
     }
 }
 
@@ -593,6 +596,11 @@ template <int R> constexpr int kFastWaves = PCT_FAST_WAVES;
 // exact squared distance >= T (1 - 2^-20): the query is accepted only if its (k+1)-th exact key lies below that.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
+// Level passes (pct_levels.hip) want to know WHY a row went to the redo list: the two top payload bits of an entry
+// carry 1 = the stencil cannot vouch for the answer (cells too small for this query), 2 = the stencil overflowed the
+// staging area (cells too large), 3 = anything else.  Plain sweeps store the bare row.
+#define PCT_REDO_ENTRY(row, why) (a.row_done ? ((row) | ((why) << 29)) : (row))
+
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
 template <int R, bool EPS, bool PRE, bool PAIR = false>
@@ -677,7 +685,10 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
         int base = 0;
         if (lane == 0) base = atomicAdd(redo_count, nq);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < nq) redo[base + lane] = row0 + lane;
+        if (lane < nq) {
+            redo[base + lane] = PCT_REDO_ENTRY(row0 + lane, 2);
+            if (a.redo_m) a.redo_m[base + lane] = m;
+        }
         if (a.stats && lane == 0) {
             atomicAdd(&a.counters[1], 1ull);
             atomicAdd(&a.counters[4], (unsigned long long)nq);
@@ -772,8 +783,12 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     if constexpr (PRE && PAIR) {
         static_assert(R == 1, "pairs: one register per list");
         unsigned* pend_b = s_pend2[w];
-        const auto push_redo = [&](int row) {
-            if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+        const auto push_redo = [&](int row, int why) {
+            if (lane == 0) {
+                const int at = atomicAdd(redo_count, 1);
+                redo[at] = PCT_REDO_ENTRY(row, why);
+                if (a.redo_m) a.redo_m[at] = m;
+            }
             ++n_redo;
         };
         for (int qi = 0; qi < nq; qi += 2) {
@@ -874,8 +889,8 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     ok_b = ok_b && found_b && T_b >= 1e-30f;
                     if (ok_b) { t_prev_f = T_b; bkey_b = (unsigned)fmin((double)T_b * (1.0 - 0x1p-20) * scale, 4294967294.0); }
                 }
-                if (!ok_a) { push_redo(row_a); T_a = 0.f; cnt_a = 0; }           // nothing passes, nothing is stored
-                if (!ok_b) { if (live_b) push_redo(row_b); T_b = 0.f; cnt_b = 0; }
+                if (!ok_a) { push_redo(row_a, 3); T_a = 0.f; cnt_a = 0; }        // nothing passes, nothing is stored
+                if (!ok_b) { if (live_b) push_redo(row_b, 3); T_b = 0.f; cnt_b = 0; }
                 if (!ok_a && !ok_b) continue;
             }
             if (!live_b) { T_b = 0.f; cnt_b = 0; }
@@ -917,15 +932,19 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 n_flush += 2;
             }
             // ---- proof obligations per query (see the single-query path below) -----------------------------------------
-            bool amb_a = false, amb_b = false;
+            bool amb_a = false, amb_b = false, sparse_a = false, sparse_b = false;
             {
                 const unsigned tau_a = (unsigned)__builtin_amdgcn_readlane((int)both.e[0], k);
                 const unsigned tau_b = (unsigned)__builtin_amdgcn_readlane((int)both.e[1], k);
-                const unsigned gk_a = min((unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi), bkey_a);
-                const unsigned gk_b = min((unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj), bkey_b);
+                const unsigned g_a = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
+                const unsigned g_b = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj);
                 const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
-                amb_a |= min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key) > gk_a;
-                amb_b |= min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key) > gk_b;
+                const unsigned need_ka = min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key);
+                const unsigned need_kb = min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key);
+                sparse_a = need_ka > g_a;
+                sparse_b = need_kb > g_b;
+                amb_a |= need_ka > min(g_a, bkey_a);
+                amb_b |= need_kb > min(g_b, bkey_b);
                 amb_a |= tau_a != kPadElem && tk_a >= key_max - 1u;
                 amb_b |= tau_b != kPadElem && tk_b >= key_max - 1u;
                 unsigned up_a = __shfl_down(both.e[0], 1), up_b = __shfl_down(both.e[1], 1);
@@ -933,8 +952,8 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 amb_a |= lane <= k && both.e[0] != kPadElem && up_a != kPadElem && ((both.e[0] ^ up_a) >> SLOT_BITS) == 0u;
                 amb_b |= lane <= k && both.e[1] != kPadElem && up_b != kPadElem && ((both.e[1] ^ up_b) >> SLOT_BITS) == 0u;
             }
-            if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a); ok_a = false; }
-            if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b); ok_b = false; }
+            if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a, sparse_a ? 1 : 3); ok_a = false; }
+            if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b, sparse_b ? 1 : 3); ok_b = false; }
             // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
 #pragma unroll
             for (int set = 0; set < 2; ++set) {
@@ -966,6 +985,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                         for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
                         if (lane == 0) a.nbr_cnt[row] = found;
                     }
+                    if (a.row_done && lane == 0) a.row_done[row] = 1;
                 }
             }
         }
@@ -1039,7 +1059,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     t = nt;
                 }
                 if (!found || !(T >= 1e-30f)) {                // no usable threshold: the exact sweep takes the query
-                    if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+                    if (lane == 0) {
+                        const int at = atomicAdd(redo_count, 1);
+                        redo[at] = PCT_REDO_ENTRY(row, 3);
+                        if (a.redo_m) a.redo_m[at] = m;
+                    }
                     ++n_redo;
                     continue;
                 }
@@ -1123,7 +1147,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     t = nt;
                 }
                 if (!found) {                                   // no usable threshold: the exact sweep takes the query
-                    if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+                    if (lane == 0) {
+                        const int at = atomicAdd(redo_count, 1);
+                        redo[at] = PCT_REDO_ENTRY(row, 3);
+                        if (a.redo_m) a.redo_m[at] = m;
+                    }
                     ++n_redo;
                     continue;
                 }
@@ -1169,10 +1197,12 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
         }
 
         // ---- is every point closer than the (k+1)-th best inside the stencil?  (key rounded up; all in key units)
+        bool sparse = false;
         {
             const unsigned gkey = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
             const unsigned tkey = tau >> SLOT_BITS;
             const unsigned need = min(tau == kPadElem ? 0xFFFFFFFFu : tkey + 1u, eps_key);
+            sparse = need > gkey;
             amb |= need > min(gkey, bkey);
             // a saturated key (a point clamped into a boundary cell from outside the grid box) says nothing
             // about the true distance
@@ -1194,7 +1224,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
         }
         if (__ballot(amb) != 0ull) {
-            if (lane == 0) redo[atomicAdd(redo_count, 1)] = row;
+            if (lane == 0) {
+                const int at = atomicAdd(redo_count, 1);
+                redo[at] = PCT_REDO_ENTRY(row, sparse ? 1 : 3);
+                if (a.redo_m) a.redo_m[at] = m;
+            }
             ++n_redo;
             continue;
         }
@@ -1234,6 +1268,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
             if (lane == 0) a.nbr_cnt[row] = found;
         }
+        if (a.row_done && lane == 0) a.row_done[row] = 1;
     }
     // statistics are opt-in: ~10^5 waves adding to the same words serialise at the memory side
     if (a.stats && lane == 0) {
@@ -1347,7 +1382,7 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     a.cell_own = (const int*)ctx->cell_own.p;
     a.own_start = (const int*)ctx->own_start.p;
     a.owned_pos = (const int*)ctx->owned_pos.p;
-    a.n_owned = ctx->q_end - ctx->q_begin;
+    a.n_owned = ctx->own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
     a.occ = (const int*)ctx->occ.p;
     a.n_occ = ctx->n_occ;
     a.n = ctx->n;
@@ -1360,6 +1395,8 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     a.nbr_pos = (int*)ctx->nbr_pos.p;
     a.nbr_dist = (float*)ctx->nbr_dist.p;
     a.nbr_cnt = eps > 0 ? (int*)ctx->nbr_cnt.p : nullptr;
+    a.row_done = ctx->own_flag || ctx->level_mode ? (int*)ctx->row_done.p : nullptr;
+    a.redo_m = a.row_done ? (int*)ctx->redo_m.p : nullptr;
     a.counters = (unsigned long long*)ctx->counters.p;
     a.stats = ctx->collect_stats ? 1 : 0;
     return a;
@@ -1367,7 +1404,7 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
 
 int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
     ctx->nbr_pitch = (k + 3) & ~3;                        // 16-byte aligned rows (the fit kernel reads int4)
-    const size_t rows = (size_t)(ctx->q_end - ctx->q_begin);     // one row per owned query
+    const size_t rows = (size_t)(ctx->own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin);     // one row per owned query
     PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, rows * ctx->nbr_pitch * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, rows * ctx->nbr_pitch * sizeof(float)));
     if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, rows * sizeof(int)));
@@ -1378,14 +1415,20 @@ int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
 
 }  // namespace
 
-int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
-    PCT_TRY(reserve_table(ctx, k, eps));
-    PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)(ctx->q_end - ctx->q_begin) + 16) * sizeof(int)));
+// phase 0: fast sweep + exact sweep of what it flagged (or, exact_only, the exact sweep of every query);
+// phase 1: fast sweep only, the flagged rows stay in ctx->redo (level passes); phase 2: exact sweep of ctx->redo
+int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, int phase) {
+    const int64_t n_rows = ctx->own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
+    if (phase != 2) {
+        PCT_TRY(reserve_table(ctx, k, eps));
+        PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
+        if (ctx->level_mode) PCT_TRY(pct_reserve(ctx, &ctx->redo_m, ((size_t)n_rows + 16) * sizeof(int)));
+    }
     KnnArgs a = make_args(ctx, k, eps, true);
     int* redo_count = (int*)ctx->counters.p + 14;            // counters buffer: 8 x u64, last int pair reserved
     int* redo = (int*)ctx->redo.p;
     const dim3 block(64 * kWavesPerBlock);
-    if (!exact_only && ctx->n_items > 0) {
+    if (!exact_only && phase != 2 && ctx->n_items > 0) {
         const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
         const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
         const int2* items = (const int2*)ctx->occ.p;
@@ -1411,8 +1454,8 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only) {
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel
     // exact pass: the flagged queries (device-side count, fixed grid) or, for testing, every query
-    {
-        const int64_t waves = exact_only ? (ctx->q_end - ctx->q_begin) : 32768;   // one query per wave for typical redo counts
+    if (phase != 1) {
+        const int64_t waves = exact_only ? n_rows : 32768;   // one query per wave for typical redo counts
         const int blocks = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
         const int* list = exact_only ? nullptr : redo;
         if (k + 1 <= 64)

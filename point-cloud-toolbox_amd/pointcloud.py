@@ -27,7 +27,7 @@ from . import _capi
 __all__ = ["PointCloud"]
 
 _ALGORITHMS = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID,
-               "grid_exact": _capi.KNN_GRID_EXACT}
+               "grid_exact": _capi.KNN_GRID_EXACT, "grid_levels": _capi.KNN_GRID_LEVELS}
 
 
 class PointCloud:

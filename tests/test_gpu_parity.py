@@ -621,3 +621,29 @@ def test_distributed_step_on_one_rank(gpu, tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0
+
+
+@pytest.mark.parametrize("kind", ["blobs", "outliers", "shell_and_core", "quantised"])
+def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind):
+    """PCT_KNN_GRID_LEVELS (each pass owns what the previous one could not answer) against the exhaustive sweep, bit
+    for bit, neighbours and curvatures, also for a shard and with the eps bound."""
+    capi = gpu["capi"]
+    for n, k, eps in ((30_000, 30, 0.0), (20_000, 70, 0.0), (25_000, 25, 0.05)):
+        pts = _stress_cloud(kind, np.random.default_rng([len(kind), n, 7]), n)
+        h = capi.Handle(0)
+        h.set_points(pts)
+        h.curvature(k, eps, capi.KNN_BRUTE)
+        ib, db, cb = h.get_neighbors(0, n, want_count=True)
+        cfb, Kb, Hb, _ = h.get_fit(0, n)
+        h.curvature(k, eps, capi.KNN_GRID_LEVELS)
+        assert h.timings()["levels"] >= 1
+        il, dl, cl = h.get_neighbors(0, n, want_count=True)
+        cfl, Kl, Hl, _ = h.get_fit(0, n)
+        assert np.array_equal(ib, il) and np.array_equal(db, dl) and np.array_equal(cb, cl), (kind, n, k, eps)
+        assert np.array_equal(cfb, cfl, equal_nan=True) and np.array_equal(Kb, Kl, equal_nan=True) and np.array_equal(Hb, Hl, equal_nan=True)
+        lo, hi = n // 3, n // 3 + n // 4
+        h.set_query_range(lo, hi)
+        h.knn(k, eps=eps, algo=capi.KNN_GRID_LEVELS)
+        i2, d2, c2 = h.get_neighbors(lo, hi, want_count=True)
+        assert np.array_equal(i2, ib[lo:hi]) and np.array_equal(d2, db[lo:hi]) and np.array_equal(c2, cb[lo:hi])
+        h.close()

@@ -19,7 +19,10 @@ clouds = {
     "lidar 1/r^2": plane(n, lambda n: (lambda r, a: np.stack([r * np.cos(a), r * np.sin(a)], 1))(0.01 * 100 ** rng.uniform(0, 1, n), rng.uniform(0, 2 * np.pi, n))),
     "gaussian blob 3d": rng.normal(size=(n, 3)),
 }
+only = sys.argv[2] if len(sys.argv) > 2 else None
 for name, p in clouds.items():
+    if only and only not in name:
+        continue
     p = np.ascontiguousarray(p, dtype=np.float32)
     h = _capi.Handle(0)
     h.set_points(p)
@@ -33,6 +36,13 @@ for name, p in clouds.items():
         t = h.timings()
         if best is None or t["total_ms"] < best["total_ms"]:
             best = t
+    lv = None
+    for _ in range(3):
+        h.curvature(50, 0.0, _capi.KNN_GRID_LEVELS)
+        t = h.timings()
+        if lv is None or t["total_ms"] < lv["total_ms"]:
+            lv = t
+    print(f"{name:22s} LEVELS total {lv['total_ms']:8.3f} ms knn {lv['knn_ms']:.3f} fit {lv['fit_ms']:.3f} levels {lv['levels']}")
     print(f"{name:22s} total {best['total_ms']:8.3f} ms  grid {best['grid_ms']:.3f} knn {best['knn_ms']:.3f} (fast {best['knn_fast_ms']:.3f}) fit {best['fit_ms']:.3f} | "
           f"iters {best['grid_iters']} m {best['occupancy']:.1f} cells {best['cells']} redo {s['redone_queries']} ovf-items {s['lds_overflows']} ring>1 {s['ring_fallbacks']}", flush=True)
     h.close()
