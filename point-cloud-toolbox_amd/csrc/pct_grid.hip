@@ -712,7 +712,7 @@ static void set_dims(pct_grid* g, const float* bbox, double a) {
 int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // measured optima on surface clouds (tools/tune_factor.py): larger cells cost candidates, smaller ones cost
     // trips to the exact sweep; the LDS staging capacity caps the large side
-    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 32 ? 0.65 : k + 1 <= 64 ? 0.55 : 0.45);
+    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : pct_default_factor(k);
     const double target = factor * (k + 1);
     // (the first pass of a chained sweep only has to be roughly right: the later passes adapt)
     const int64_t cell_cap = (int64_t)1 << (ctx->level_mode ? 24 : 27);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 #include "../../include/pct_hip.h"
 
@@ -123,6 +124,29 @@ struct pct_ctx {
 };
 
 int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...);
+
+// The fast sweep sorts <= 64 survivors in one register per lane (R = 1) or <= 128 in two (R = 2).  R = 1 would hold
+// k + 1 <= 64, but near that limit the window k+1 <= count <= 64 for the threshold gets narrow and the larger cells
+// overflow the 512-slot staging area: from k + 1 > kFastR1Max on, R = 2 (768 slots, window up to 128) is faster.
+#ifndef PCT_FAST_R1_MAX
+#define PCT_FAST_R1_MAX 64
+#endif
+inline int pct_fast_r1_max() {
+    static const int v = [] { const char* e = getenv("PCT_FAST_R1_MAX"); const int x = e ? atoi(e) : PCT_FAST_R1_MAX; return x < 2 ? 2 : x > 64 ? 64 : x; }();
+    return v;
+}
+// cell occupancy (points sharing a point's cell) the grid is sized for, as a multiple of k + 1 (tools/tune_factor.py)
+// R = 1: 0.56 (k + 1) but at most ~29.5 points per cell -- beyond that the 27-cell stencil of a surface outgrows the
+// 512 staged slots (measured optimum 0.55-0.60 at k = 40, 0.55 at 50, 0.50 at 56 and 60)
+inline double pct_default_factor(int k) {
+    if (k + 1 <= 32) return 0.65;
+    if (k + 1 > pct_fast_r1_max()) {                  // R = 2 (768 slots): 0.52 up to k ~ 84, 0.45 at 100, 0.40 at 127
+        const double n = k + 1;
+        return n <= 85 ? 0.52 : n <= 101 ? 0.52 - 0.07 * (n - 85) / 16.0 : 0.45 - 0.05 * (n - 101) / 27.0;
+    }
+    const double f = 29.5 / (k + 1);
+    return f < 0.56 ? f : 0.56;
+}
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);
 
 #define PCT_HIP(ctx, call)                                                        \

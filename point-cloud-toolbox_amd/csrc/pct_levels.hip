@@ -180,7 +180,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
     const int64_t nq = ctx->q_end - ctx->q_begin;
     if (ctx->n >= ((int64_t)1 << 29)) return pct_fail(ctx, PCT_ERR_INVALID, "the chained sweep handles clouds below 2^29 points");
     const int pitch = (k + 3) & ~3;
-    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : (k + 1 <= 32 ? 0.65 : k + 1 <= 64 ? 0.55 : 0.45);
+    const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : pct_default_factor(k);
     const double target = factor * (k + 1);
     constexpr int kMaxPasses = 14;
     const int64_t enough = nq / 256 > 1024 ? nq / 256 : 1024;      // leftovers of this size go to the exact sweep
