@@ -136,16 +136,17 @@ inline int pct_fast_r1_max() {
     return v;
 }
 // cell occupancy (points sharing a point's cell) the grid is sized for, as a multiple of k + 1 (tools/tune_factor.py)
-// R = 1: 0.56 (k + 1) but at most ~29.5 points per cell -- beyond that the 27-cell stencil of a surface outgrows the
-// 512 staged slots (measured optimum 0.55-0.60 at k = 40, 0.55 at 50, 0.50 at 56 and 60)
+// R = 1: the optimum is set by the 512 staged slots, not by k: ~27 points per cell for k <= 47 (measured optimum
+// 2.4 (k+1) at k = 10, 1.2-1.4 at 20, 0.85 at 30, 0.55-0.60 at 40), rising to ~29.5 from k = 52 on (0.55 at 50, 0.50 at
+// 56 and 60): larger cells mean fewer work items and ring fallbacks until the 27-cell stencil of a surface outgrows
+// the staging area.
 inline double pct_default_factor(int k) {
-    if (k + 1 <= 32) return 0.65;
-    if (k + 1 > pct_fast_r1_max()) {                  // R = 2 (768 slots): 0.52 up to k ~ 84, 0.45 at 100, 0.40 at 127
-        const double n = k + 1;
-        return n <= 85 ? 0.52 : n <= 101 ? 0.52 - 0.07 * (n - 85) / 16.0 : 0.45 - 0.05 * (n - 101) / 27.0;
+    if (k + 1 <= pct_fast_r1_max()) {
+        const double per_cell = k <= 47 ? 27.0 : k >= 52 ? 29.5 : 27.0 + 0.5 * (k - 47);
+        return per_cell / (k + 1);
     }
-    const double f = 29.5 / (k + 1);
-    return f < 0.56 ? f : 0.56;
+    const double n = k + 1;                           // R = 2 (768 slots): 0.52 up to k ~ 84, 0.45 at 100, 0.40 at 127
+    return n <= 85 ? 0.52 : n <= 101 ? 0.52 - 0.07 * (n - 85) / 16.0 : 0.45 - 0.05 * (n - 101) / 27.0;
 }
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);
 
