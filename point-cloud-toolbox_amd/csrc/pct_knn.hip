@@ -571,12 +571,24 @@ __device__ __forceinline__ void fast_sort_from(FastK<R>& t, const SortLanes& c) 
     if constexpr (SIZE < 64 * R) fast_sort_from<R, SIZE * 2>(t, c);
 }
 
-// NSETS independent ascending sorts of 64 elements each (one register per set), level by level side by side
-template <int NSETS, int SIZE>
-__device__ __forceinline__ void fast_sort_sets(FastK<NSETS>& t, const SortLanes& c) {
-    fast_flip<NSETS, SIZE>(t, c);
-    fast_strides<NSETS, SIZE / 4>(t, c);
-    if constexpr (SIZE < 64) fast_sort_sets<NSETS, SIZE * 2>(t, c);
+// NSETS independent ascending sorts of 64 R elements each (set s = registers s R .. s R + R - 1), level by level side
+// by side: the lane-level steps treat all NSETS R registers alike, only the 128-wide flip pairs registers per set
+template <int R, int NSETS, int SIZE>
+__device__ __forceinline__ void fast_sort_sets(FastK<NSETS * R>& t, const SortLanes& c) {
+    if constexpr (SIZE <= 64) {
+        fast_flip<NSETS * R, SIZE>(t, c);
+    } else {
+        static_assert(SIZE == 128 && R == 2, "two registers per set at most");
+#pragma unroll
+        for (int s = 0; s < NSETS; ++s) {
+            const unsigned lo_rev = (unsigned)__builtin_amdgcn_ds_bpermute(c.a63, (int)t.e[2 * s]);
+            const unsigned hi_rev = (unsigned)__builtin_amdgcn_ds_bpermute(c.a63, (int)t.e[2 * s + 1]);
+            t.e[2 * s] = min(t.e[2 * s], hi_rev);
+            t.e[2 * s + 1] = max(t.e[2 * s + 1], lo_rev);
+        }
+    }
+    fast_strides<NSETS * R, (SIZE / 4 < 32 ? SIZE / 4 : 32)>(t, c);
+    if constexpr (SIZE < 64 * R) fast_sort_sets<R, NSETS, SIZE * 2>(t, c);
 }
 
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     __shared__ float s_cy[kFastWaves<R>][CAP];        // 12 B per candidate
     __shared__ float s_cz[kFastWaves<R>][CAP];
     __shared__ unsigned s_pend[kFastWaves<R>][64 * R];
-    __shared__ unsigned s_pend2[kFastWaves<R>][PAIR ? 64 * R : 1];    // list of the second query of a pair
+    __shared__ unsigned short s_pend2[kFastWaves<R>][PAIR ? 64 * R : 2];    // survivors of the second query of a pair (16 bits: R = 2 stays at 4 blocks per CU)
     __shared__ int s_offc[kFastWaves<R>][16];          // sorted position - flat slot, per non-empty run
 
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -781,8 +793,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
 
     if constexpr (PRE && PAIR) {
-        static_assert(R == 1, "pairs: one register per list");
-        unsigned* pend_b = s_pend2[w];
+        unsigned short* pend_b = s_pend2[w];
         const auto push_redo = [&](int row, int why) {
             if (lane == 0) {
                 const int at = atomicAdd(redo_count, 1);
@@ -895,7 +906,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
             if (!live_b) { T_b = 0.f; cnt_b = 0; }
             // ---- compact the slots of the survivors of both queries, then exact keys for them only ------------------
-            FastK<2> both;
+            FastK<2 * R> both;                 // set 0 = query a (registers 0 .. R-1), set 1 = query b
             {
                 int base_a = 0, base_b = 0;
                 wave_lds_sync();
@@ -905,37 +916,49 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                         const bool pa = ap_a[b] < T_a, pb = ap_b[b] < T_b;
                         const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
                         if (pa) pend[base_a + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0))] = (unsigned)(b * 64 + lane);
-                        if (pb) pend_b[base_b + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0))] = (unsigned)(b * 64 + lane);
+                        if (pb) pend_b[base_b + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0))] = (unsigned short)(b * 64 + lane);
                         base_a += (int)__popcll(ma);
                         base_b += (int)__popcll(mb);
                     }
                 }
                 wave_lds_sync();
                 const double qax = (double)ax, qay = (double)ay, qaz = (double)az, qbx = (double)bx, qby = (double)by, qbz = (double)bz;
-                unsigned e_a = kPadElem, e_b = kPadElem;
-                if (lane < cnt_a) {
-                    const int j = (int)pend[lane];
-                    const double dx = (double)cand_x[j] - qax, dy = (double)cand_y[j] - qay, dz = (double)cand_z[j] - qaz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    unsigned e_a = kPadElem, e_b = kPadElem;
+                    if (i < cnt_a) {
+                        const int j = (int)pend[i];
+                        const double dx = (double)cand_x[j] - qax, dy = (double)cand_y[j] - qay, dz = (double)cand_z[j] - qaz;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
+                    }
+                    if (i < cnt_b) {
+                        const int j = (int)pend_b[i];
+                        const double dx = (double)cand_x[j] - qbx, dy = (double)cand_y[j] - qby, dz = (double)cand_z[j] - qbz;
+                        const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
+                    }
+                    both.e[r] = e_a;
+                    both.e[R + r] = e_b;
                 }
-                if (lane < cnt_b) {
-                    const int j = (int)pend_b[lane];
-                    const double dx = (double)cand_x[j] - qbx, dy = (double)cand_y[j] - qby, dz = (double)cand_z[j] - qbz;
-                    const double d2 = (dx * dx + dy * dy) + dz * dz;
-                    if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
-                }
-                both.e[0] = e_a;
-                both.e[1] = e_b;
                 wave_lds_sync();
-                fast_sort_sets<2, 2>(both, sort_dir);
+                fast_sort_sets<R, 2, 2>(both, sort_dir);
                 n_flush += 2;
             }
             // ---- proof obligations per query (see the single-query path below) -----------------------------------------
             bool amb_a = false, amb_b = false, sparse_a = false, sparse_b = false;
             {
-                const unsigned tau_a = (unsigned)__builtin_amdgcn_readlane((int)both.e[0], k);
-                const unsigned tau_b = (unsigned)__builtin_amdgcn_readlane((int)both.e[1], k);
+                unsigned tau_a, tau_b;         // element k of each list = the (k+1)-th nearest (padding if fewer exist)
+                {
+                    const int sl = k >> 6, src = k & 63;
+                    unsigned va = both.e[0], vb = both.e[R];
+#pragma unroll
+                    for (int r = 1; r < R; ++r)
+                        if (sl == r) { va = both.e[r]; vb = both.e[R + r]; }
+                    tau_a = (unsigned)__builtin_amdgcn_readlane((int)va, src);
+                    tau_b = (unsigned)__builtin_amdgcn_readlane((int)vb, src);
+                }
                 const unsigned g_a = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
                 const unsigned g_b = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj);
                 const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
@@ -947,28 +970,45 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 amb_b |= need_kb > min(g_b, bkey_b);
                 amb_a |= tau_a != kPadElem && tk_a >= key_max - 1u;
                 amb_b |= tau_b != kPadElem && tk_b >= key_max - 1u;
-                unsigned up_a = __shfl_down(both.e[0], 1), up_b = __shfl_down(both.e[1], 1);
-                if (lane == 63) { up_a = kPadElem; up_b = kPadElem; }
-                amb_a |= lane <= k && both.e[0] != kPadElem && up_a != kPadElem && ((both.e[0] ^ up_a) >> SLOT_BITS) == 0u;
-                amb_b |= lane <= k && both.e[1] != kPadElem && up_b != kPadElem && ((both.e[1] ^ up_b) >> SLOT_BITS) == 0u;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    unsigned up_a = __shfl_down(both.e[r], 1), up_b = __shfl_down(both.e[R + r], 1);     // element i+1
+                    if (r + 1 < R) {
+                        const unsigned na = (unsigned)__builtin_amdgcn_readlane((int)both.e[r + 1 < R ? r + 1 : r], 0);
+                        const unsigned nb = (unsigned)__builtin_amdgcn_readlane((int)both.e[R + (r + 1 < R ? r + 1 : r)], 0);
+                        if (lane == 63) { up_a = na; up_b = nb; }
+                    } else if (lane == 63) {
+                        up_a = kPadElem;
+                        up_b = kPadElem;
+                    }
+                    const int i = lane + 64 * r;
+                    amb_a |= i <= k && both.e[r] != kPadElem && up_a != kPadElem && ((both.e[r] ^ up_a) >> SLOT_BITS) == 0u;
+                    amb_b |= i <= k && both.e[R + r] != kPadElem && up_b != kPadElem && ((both.e[R + r] ^ up_b) >> SLOT_BITS) == 0u;
+                }
             }
             if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a, sparse_a ? 1 : 3); ok_a = false; }
             if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b, sparse_b ? 1 : 3); ok_b = false; }
             // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
 #pragma unroll
             for (int set = 0; set < 2; ++set) {
-                const unsigned e = both.e[set];
-                const bool real = e != kPadElem;
-                const unsigned* lst = set == 0 ? pend : pend_b;
-                const int j = (int)lst[e & ((1u << SLOT_BITS) - 1u)] & (CAP_POW2 - 1);
-                const unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
-                const unsigned t = (code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u;
-                const int pos_real = j + offc[t];
                 const bool ok = set == 0 ? ok_a : ok_b;
                 const int row = set == 0 ? row_a : row_b;
-                if (ok) {
-                    int found = 0;
-                    if (lane >= 1 && lane <= k) {
+                int found = 0;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int i = lane + 64 * r;
+                    const unsigned e = both.e[set * R + r];
+                    const bool real = e != kPadElem;
+                    const unsigned at = e & ((1u << SLOT_BITS) - 1u);
+                    const int j = (set == 0 ? (int)pend[at] : (int)pend_b[at]) & (CAP_POW2 - 1);
+                    unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+                    if constexpr ((CAP / 64 + 7) / 8 > 1) {
+                        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
+                        code = (j >> 9) ? hi : code;
+                    }
+                    const unsigned t = (code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u;
+                    const int pos_real = j + offc[t];
+                    if (ok && i >= 1 && i <= k) {
                         int pos = -1;
                         float dist = INFINITY;
                         if (real) {
@@ -977,10 +1017,12 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                             dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
                             pos = pos_real;
                         }
-                        a.nbr_pos[(int64_t)row * a.pitch + (lane - 1)] = pos;
-                        a.nbr_dist[(int64_t)row * a.pitch + (lane - 1)] = dist;
+                        a.nbr_pos[(int64_t)row * a.pitch + (i - 1)] = pos;
+                        a.nbr_dist[(int64_t)row * a.pitch + (i - 1)] = dist;
                         found += real;
                     }
+                }
+                if (ok) {
                     if (a.nbr_cnt) {
                         for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
                         if (lane == 0) a.nbr_cnt[row] = found;
@@ -1436,10 +1478,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         static const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;          // tuning aid
-#define PCT_FAST_PAIR(E_) \
-    hipLaunchKernelGGL((k_knn_fast<1, E_, true, true>), grid1, block1, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        if (r1 && !e && pre && !no_pair) PCT_FAST_PAIR(false);
-        else if (r1 && e && pre && !no_pair) PCT_FAST_PAIR(true);
+#define PCT_FAST_PAIR(R_, E_, GRID_, BLOCK_) \
+    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (r1 && !e && pre && !no_pair) PCT_FAST_PAIR(1, false, grid1, block1);
+        else if (r1 && e && pre && !no_pair) PCT_FAST_PAIR(1, true, grid1, block1);
+        else if (!r1 && !e && pre && !no_pair) PCT_FAST_PAIR(2, false, grid2, block2);
+        else if (!r1 && e && pre && !no_pair) PCT_FAST_PAIR(2, true, grid2, block2);
         else if (r1 && !e && pre) PCT_FAST(1, false, true, grid1, block1);
         else if (r1 && e && pre) PCT_FAST(1, true, true, grid1, block1);
         else if (r1 && !e) PCT_FAST(1, false, false, grid1, block1);
