@@ -29,8 +29,9 @@ def test_constructor_attributes(built):
     pc = PC(points=P, normals=np.zeros((50, 0)), k_neighbors=7)
     assert pc.points is P and pc.points.dtype == np.float64      # kept as given (pct:38)
     assert pc.num_points == 50 and pc.num_features == 3 and pc.k_neighbors == 7
-    assert pc.l1_norm == np.linalg.norm(P, 1)
-    assert np.isclose(pc.l2_norm, np.linalg.norm(P, 2), rtol=1e-12, atol=0)     # Gram-matrix route instead of the SVD
+    # one transposed pass instead of numpy's three (pointcloud._matrix_norms): equal up to rounding
+    assert np.isclose(pc.l1_norm, np.linalg.norm(P, 1), rtol=1e-12, atol=0)
+    assert np.isclose(pc.l2_norm, np.linalg.norm(P, 2), rtol=1e-12, atol=0)
     assert pc.infinity_norm == np.linalg.norm(P, np.inf)
     assert pc.random_indexes == [] and pc.output_path == './output/'
 
