@@ -228,97 +228,64 @@ __global__ __launch_bounds__(kBlock) void k_box_stats(const float4* __restrict__
 // ---- sharded handles: keep only the points near the owned range ------------------------------------------------
 // The candidate set of a handle that owns rows [q_begin, q_end) is the whole cloud, but only the points inside
 // the owned rows' bounding box plus a margin can be neighbours (the sweep verifies that per query, see
-// pct_grid::lim_lo).  Order-preserving compaction in two passes over chunks of kCullChunk rows.
+// pct_grid::lim_lo).  One pass: the owned rows go to the front of the packed array in their own order, the kept
+// others behind them in whatever order the blocks arrive (one counter increment per 4096-row chunk).
 constexpr int kCullChunk = kBlock * 16;
 
-__global__ __launch_bounds__(kBlock) void k_cull_count(const float* __restrict__ xyz, int64_t n, Box3 box,
-                                                       int* __restrict__ chunk_cnt, PackRed* __restrict__ red) {
-    __shared__ int s_c[kBlock / 64];
-    const int64_t base = (int64_t)blockIdx.x * kCullChunk;
-    int c = 0, bad = 0;
-    for (int r = 0; r < 16; ++r) {
-        const int64_t i = base + r * kBlock + threadIdx.x;
-        if (i < n) {
-            const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-            bad |= !(isfinite(x) && isfinite(y) && isfinite(z));
-            c += in_box(box, x, y, z);
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    bad = __any(bad);
-    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        int t = 0;
-        for (int i = 0; i < kBlock / 64; ++i) t += s_c[i];
-        chunk_cnt[blockIdx.x] = t;
-    }
-    if (bad && (threadIdx.x & 63) == 0) atomicOr(&red->bad, 1);
-}
-
-// single block: exclusive scan of the chunk counts in place, total to cnt[nchunk]
-__global__ __launch_bounds__(1024) void k_scan_chunks(int* __restrict__ cnt, int nchunk, int* __restrict__ host_total) {
-    __shared__ int sh[1024];
-    __shared__ int carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < nchunk; base += 1024) {
-        const int i = base + threadIdx.x;
-        const int v = i < nchunk ? cnt[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (int o = 1; o < 1024; o <<= 1) {
-            int a = 0;
-            if ((int)threadIdx.x >= o) a = sh[threadIdx.x - o];
-            __syncthreads();
-            sh[threadIdx.x] += a;
-            __syncthreads();
-        }
-        const int incl = sh[threadIdx.x], c = carry;
-        if (i < nchunk) cnt[i] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) { cnt[nchunk] = carry; *host_total = carry; }
-}
-
-__global__ __launch_bounds__(kBlock) void k_cull_write(const float* __restrict__ xyz, int64_t n, Box3 box,
-                                                       const int* __restrict__ chunk_off, int64_t q_begin,
-                                                       float4* __restrict__ pts4, PackRed* __restrict__ red,
-                                                       PackRed* __restrict__ parts) {
-    __shared__ int s_w[kBlock / 64];
+__global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ xyz, int64_t n, Box3 box, int64_t q_begin,
+                                                      int64_t q_end, float4* __restrict__ pts4, unsigned* __restrict__ kept_others,
+                                                      PackRed* __restrict__ red, PackRed* __restrict__ parts) {
+    __shared__ int s_cnt[16][kBlock / 64];
+    __shared__ int s_base;
     const float sh[3] = {0.f, 0.f, 0.f};
     PackAcc acc;
     acc.init();
     const int64_t base = (int64_t)blockIdx.x * kCullChunk;
-    const int w = threadIdx.x >> 6;
-    int running = chunk_off[blockIdx.x];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t n_owned = q_end - q_begin;
+    float px[16], py[16], pz[16];
+    unsigned keep_bits = 0;
+    int bad = 0;
+#pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
-        float x = 0.f, y = 0.f, z = 0.f;
+        px[r] = py[r] = pz[r] = 0.f;
         bool keep = false;
         if (i < n) {
-            x = xyz[3 * i + 0]; y = xyz[3 * i + 1]; z = xyz[3 * i + 2];
-            keep = in_box(box, x, y, z);
+            px[r] = xyz[3 * i + 0]; py[r] = xyz[3 * i + 1]; pz[r] = xyz[3 * i + 2];
+            bad |= !(isfinite(px[r]) && isfinite(py[r]) && isfinite(pz[r]));
+            if (i >= q_begin && i < q_end) {
+                pts4[i - q_begin] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
+                acc.add(px[r], py[r], pz[r], sh);
+            } else {
+                keep = in_box(box, px[r], py[r], pz[r]);
+            }
         }
+        keep_bits |= keep ? 1u << r : 0u;
         const unsigned long long m = __ballot(keep);
-        if ((threadIdx.x & 63) == 0) s_w[w] = (int)__popcll(m);
-        __syncthreads();
-        int before = 0, total = 0;
-        for (int j = 0; j < kBlock / 64; ++j) {
-            before += j < w ? s_w[j] : 0;
-            total += s_w[j];
-        }
-        if (keep) {
-            const int at = running + before + (int)__popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-            pts4[at] = make_float4(x, y, z, __int_as_float((int)i));
-            acc.add(x, y, z, sh);
-            if (i == q_begin) red->g_begin = at;
-        }
-        running += total;
-        __syncthreads();
+        if (lane == 0) s_cnt[r][w] = (int)__popcll(m);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {            // exclusive prefix over (round, wave), one counter increment per chunk
+        int total = 0;
+        for (int r = 0; r < 16; ++r)
+            for (int v = 0; v < kBlock / 64; ++v) { const int c = s_cnt[r][v]; s_cnt[r][v] = total; total += c; }
+        s_base = total ? (int)atomicAdd(kept_others, (unsigned)total) : 0;
+    }
+    __syncthreads();
+    const int64_t out0 = n_owned + s_base;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const bool keep = (keep_bits >> r) & 1u;
+        const unsigned long long m = __ballot(keep);
+        if (keep) {
+            const int64_t i = base + r * kBlock + threadIdx.x;
+            const int64_t at = out0 + s_cnt[r][w] + (int)__popcll(m & ((1ull << lane) - 1ull));
+            pts4[at] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
+            acc.add(px[r], py[r], pz[r], sh);
+        }
+    }
+    if (__any(bad) && lane == 0) atomicOr(&red->bad, 1);
     acc.commit(parts + blockIdx.x);
 }
 
@@ -617,25 +584,22 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     *kept_box = box;
 
     const int nchunk = (int)((n + kCullChunk - 1) / kCullChunk);
-    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nchunk + 1) * sizeof(int)));
+    PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));           // worst case: everything is kept
+    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 64));
     PCT_TRY(red_reset(ctx, nchunk));
-    hipLaunchKernelGGL(k_cull_count, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box,
-                       (int*)ctx->scan_tmp.p, (PackRed*)ctx->red.p);
-    hipLaunchKernelGGL(k_scan_chunks, dim3(1), dim3(1024), 0, ctx->stream, (int*)ctx->scan_tmp.p, nchunk, (int*)(ctx->pin + 160));
-    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const int kept = *(const int*)(ctx->pin + 160);
+    PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, sizeof(unsigned), ctx->stream));
+    hipLaunchKernelGGL(k_cull_pack, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end,
+                       (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
-    PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)kept * sizeof(float4)));
-    hipLaunchKernelGGL(k_cull_write, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box,
-                       (const int*)ctx->scan_tmp.p, ctx->q_begin, (float4*)ctx->pts4.p, (PackRed*)ctx->red.p, red_parts(ctx));
-    PCT_HIP(ctx, hipGetLastError());
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     PCT_TRY(red_read(ctx, nchunk, red, bbox));
     if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
-    if ((int64_t)red->cnt != kept || kept < n_owned)
-        return pct_fail(ctx, PCT_ERR_INVALID, "cull pass kept %lld / counted %d points", (long long)red->cnt, kept);
+    const int64_t kept = n_owned + (int64_t)*(const unsigned*)(ctx->pin + 160);
+    if ((int64_t)red->cnt != kept || kept > n)
+        return pct_fail(ctx, PCT_ERR_INVALID, "cull pass kept %lld / counted %lld points", (long long)red->cnt, (long long)kept);
     ctx->pts4_valid = false;                 // pts4 is not the full public-order pack
     ctx->n_grid = kept;
-    ctx->g_begin = red->g_begin;
+    ctx->g_begin = 0;                        // the owned rows lead the packed array
     ctx->culled = kept < n;
     return PCT_OK;
 }
