@@ -280,6 +280,7 @@ int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     if (again) {                      // rare: redo with every point in the grid
         ctx->no_cull = true;
         ctx->retries = 1;
+        ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
         PCT_TRY(run_knn(ctx, k, eps, algo));
         PCT_TRY(finish_knn_stats(ctx, &again));
     }
@@ -313,6 +314,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         if (!again) break;
         ctx->no_cull = true;          // rare: redo with every point in the grid
         ctx->retries = 1;
+        ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
     }
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
@@ -566,6 +568,7 @@ int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {
         if (!again) break;
         ctx->no_cull = true;
         ctx->retries = 1;
+        ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
     }
     ctx->fit_valid = false;
     return PCT_OK;

@@ -46,6 +46,9 @@ struct pct_ctx {
     int64_t n_grid = 0, g_begin = 0;
     bool culled = false;           // the grid holds fewer than n points
     bool no_cull = false;          // set after a sweep met a query the kept points cannot answer
+    float cull_box[6] = {0, 0, 0, 0, 0, 0};    // box of the last sharded pack (reused for the next similar cloud)
+    bool cull_box_valid = false;
+    int64_t cull_box_n = 0, cull_box_q0 = 0, cull_box_q1 = 0;
     int32_t retries = 0;
     double hint_edge = 0, hint_guess = 0, hint_target = 0;   // warm start of the cell-size search (pct_build_grid)
     // density-adaptive sweep (pct_levels.hip): the queries one pass could not answer are re-owned by the next
