@@ -524,11 +524,17 @@ static int red_reset(pct_ctx* ctx, int n_parts) {
     return PCT_OK;
 }
 
-// folds the n_parts block records of the pass just launched and reads the result back
-static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
+// folds the n_parts block records of the pass just launched (the result also lands in pinned host memory)
+static int red_fold(pct_ctx* ctx, int n_parts) {
     hipLaunchKernelGGL(k_pack_final, dim3(1), dim3(kBlock), 0, ctx->stream, (const PackRed*)red_parts(ctx), n_parts,
                        (PackRed*)ctx->red.p, (PackRed*)ctx->pin);
     PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+// ... and reads the result back
+static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
+    PCT_TRY(red_fold(ctx, n_parts));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->pin, sizeof(*out));
     for (int a = 0; a < 6; ++a) bbox[a] = order_float(out->bb[a]);
@@ -536,7 +542,9 @@ static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
 }
 
 // every point, public order
-static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red) {
+// defer: do not wait for the result (the caller builds on the previous call's box and checks at its next
+// synchronisation, pct_build_grid)
+static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red, bool defer = false) {
     const int64_t n = ctx->n;
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));
     const int nb = grid_1d(n, kBlock * 4, 512);
@@ -544,8 +552,12 @@ static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red) {
     hipLaunchKernelGGL(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
                        ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
-    PCT_TRY(red_read(ctx, nb, red, bbox));
-    if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    if (defer) {
+        PCT_TRY(red_fold(ctx, nb));
+    } else {
+        PCT_TRY(red_read(ctx, nb, red, bbox));
+        if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    }
     ctx->pts4_valid = true;
     ctx->n_grid = n;
     ctx->g_begin = ctx->q_begin;
@@ -704,11 +716,22 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     Box3 kept_box = {};
     const bool try_cull = !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !getenv("PCT_NO_CULL");
     ctx->tm.grid_iters = 0;
-    if (try_cull)
+    // Speculation: a handle fed a stream of similar clouds builds the cell list over the (trimmed) box of the previous
+    // call without waiting for the new bounding box -- any box is a valid grid box, points outside are clamped into
+    // the boundary cells -- and checks the new box at the synchronisation that ends the first pass.  One host round
+    // trip less per build.
+    bool spec = !try_cull && !own_flag && !ctx->level_mode && ctx->hint_edge > 0 && ctx->spec_valid && ctx->spec_n == ctx->n &&
+                !getenv("PCT_NO_SPEC");
+    if (try_cull) {
         PCT_TRY(pack_near_owned(ctx, target, bbox, &red, &kept_box));
-    else
+        PCT_TRY(trim_box(ctx, red, bbox));
+    } else if (spec) {
+        PCT_TRY(pack_all(ctx, bbox, &red, true));
+        for (int a = 0; a < 6; ++a) bbox[a] = ctx->spec_bbox[a];
+    } else {
         PCT_TRY(pack_all(ctx, bbox, &red));
-    PCT_TRY(trim_box(ctx, red, bbox));
+        PCT_TRY(trim_box(ctx, red, bbox));
+    }
     const bool sub_box = ctx->level_edge > 0 && ctx->level_box_valid;
     if (sub_box) {
         // a fast level pass only needs cells around its owned points: box = their bbox + 2.5 edges (their stencils
@@ -801,6 +824,21 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
         PCT_HIP(ctx, hipGetLastError());
         PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (spec) {                      // the deferred pack result is in: was the old box still right?
+            spec = false;
+            memcpy(&red, ctx->pin, sizeof(red));
+            if (red.bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+            bool same = true;
+            for (int ax = 0; ax < 3; ++ax) {
+                const float lo = order_float(red.bb[ax]), hi = order_float(red.bb[3 + ax]);
+                const float tol = 0.02f * (ctx->spec_raw[3 + ax] - ctx->spec_raw[ax]) + 1e-30f;
+                same = same && fabsf(lo - ctx->spec_raw[ax]) <= tol && fabsf(hi - ctx->spec_raw[3 + ax]) <= tol;
+            }
+            if (!same) {                 // a different cloud: start over the regular way
+                ctx->spec_valid = false;
+                return pct_build_grid(ctx, k, eps);
+            }
+        }
         const unsigned long long s2 = ((const ScanTotals*)(ctx->pin + 128))->sumsq;
         tot = ((const ScanTotals*)(ctx->pin + 128))->tot;
         ++iters;
@@ -836,6 +874,13 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     ctx->tm.cell_size = g.cell;
     ctx->tm.grid_points = n;
     ctx->tm.occupancy = m_last;
+    if (!try_cull && !own_flag && !ctx->level_mode) {       // remember the box for the next similar cloud
+        for (int a2 = 0; a2 < 6; ++a2) ctx->spec_bbox[a2] = bbox[a2];
+        if (red.cnt > 0)                  // raw bounding box of this cloud (before trimming)
+            for (int a2 = 0; a2 < 6; ++a2) ctx->spec_raw[a2] = order_float(red.bb[a2]);
+        ctx->spec_n = ctx->n;
+        ctx->spec_valid = true;
+    }
     if (m_last > 0 && !level_pass) {        // what the heuristic first guess should have been for this cloud
         ctx->hint_edge = g.cell * pow(target / m_last, 1.0 / d_last);
         ctx->hint_guess = first_guess_raw;

@@ -51,6 +51,10 @@ struct pct_ctx {
     int64_t cull_box_n = 0, cull_box_q0 = 0, cull_box_q1 = 0;
     int32_t retries = 0;
     double hint_edge = 0, hint_guess = 0, hint_target = 0;   // warm start of the cell-size search (pct_build_grid)
+    float spec_bbox[6] = {0, 0, 0, 0, 0, 0};   // grid box of the last plain build (trimmed), reused speculatively
+    float spec_raw[6] = {0, 0, 0, 0, 0, 0};    // raw bounding box of that cloud
+    int64_t spec_n = 0;
+    bool spec_valid = false;
     // density-adaptive sweep (pct_levels.hip): the queries one pass could not answer are re-owned by the next
     // pass, which sizes its cells for THEM
     const void* own_flag = nullptr; // device float (n): wanted log2 cell edge of every unanswered point (NaN = answered); null = ownership by index range
