@@ -101,7 +101,8 @@ class ShardedCurvature:
         """Block until the exchange started by ``begin_exchange`` has filled ``out``."""
         import torch
         ticket.wait()
-        torch.cuda.current_stream(out.device).synchronize()
+        if out.device.type == "cuda":
+            torch.cuda.current_stream(out.device).synchronize()
         return out
 
     def download(self):

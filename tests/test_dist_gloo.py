@@ -76,3 +76,44 @@ def test_sharded_path_requires_a_device_or_checker(built):
     from point_cloud_toolbox_amd.dist import ShardedCurvature
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ShardedCurvature(100, 5, 0, 1)
+
+
+def _pipeline_worker(rank, world, port, n, steps, out_dir):
+    """bench.py's multi-GPU step pattern on CPU tensors: the exchange of cloud i+1 is started before cloud i is
+    consumed, two gather buffers alternate."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    import pointCloudToolbox  # noqa: F401
+    from point_cloud_toolbox_amd import shapes
+    from point_cloud_toolbox_amd.dist import ShardedCurvature, shard_range
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    lo, hi = shard_range(n, rank, world)
+    sc = ShardedCurvature(n, 5, rank, world, compute=lambda *a: None)
+    bufs = [torch.empty((n, 3), dtype=torch.float32) for _ in range(2)]
+    clouds = [torch.from_numpy(shapes.torus_scan_order(n, world, rank, seed=100 + i)) for i in range(steps + 1)]
+    seen = []
+    ticket = sc.begin_exchange(clouds[0], bufs[0])
+    for i in range(steps):
+        cur = sc.end_exchange(ticket, bufs[i % 2])
+        ticket = sc.begin_exchange(clouds[i + 1], bufs[(i + 1) % 2])      # runs while `cur` is being consumed
+        seen.append(cur.clone().numpy())
+    sc.end_exchange(ticket, bufs[steps % 2])
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "pipe.npz"), *seen)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_double_buffered_exchange_delivers_every_cloud_intact(tmp_path):
+    import torch.multiprocessing as mp
+    import pointCloudToolbox  # noqa: F401
+    from point_cloud_toolbox_amd import shapes
+
+    world, n, steps, port = 2, 4000, 5, _free_port()
+    mp.spawn(_pipeline_worker, args=(world, port, n, steps, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "pipe.npz"))
+    for i in range(steps):
+        want = np.concatenate([shapes.torus_scan_order(n, world, r, seed=100 + i) for r in range(world)])
+        assert np.array_equal(got[f"arr_{i}"], want), f"cloud {i}"
