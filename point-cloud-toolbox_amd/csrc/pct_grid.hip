@@ -868,6 +868,9 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         g.lim_lo[ax] = ctx->culled ? ((double)kept_box.lo[ax] - o) * g.inv_cell : -INFINITY;
         g.lim_hi[ax] = ctx->culled ? ((double)kept_box.hi[ax] - o) * g.inv_cell : INFINITY;
     }
+    if (getenv("PCT_GRID_DEBUG"))
+        fprintf(stderr, "[grid] box [%g %g %g]-[%g %g %g] edge %g dims %d x %d x %d = %lld cells, %d passes, occupancy %.1f, items %d\n", bbox[0],
+                bbox[1], bbox[2], bbox[3], bbox[4], bbox[5], g.cell, g.nx, g.ny, g.nz, (long long)g.ncell, iters, m_last, tot.y);
     ctx->grid = g;
     ctx->tm.grid_iters += iters;
     ctx->tm.cells = g.ncell;

@@ -288,44 +288,56 @@ struct Sweep {
 // the closest points and the (k+1)-th distance tightens early.
 __constant__ signed char kRowOrder[9][2] = {{0, 0}, {0, -1}, {0, 1}, {-1, 0}, {1, 0}, {-1, -1}, {-1, 1}, {1, -1}, {1, 1}};
 
-// Iterator over the x-runs of the cube shell of radius `ring` around cell (cx,cy,cz); ring 1 with full == true
-// enumerates the whole 27-cell cube.  The run bounds of up to 64 (dz,dy) rows are fetched by the 64 lanes in
-// parallel (one memory round trip per 64 rows instead of two dependent scalar loads per row); the runs are then
-// handed out one 64-candidate step at a time, wave-uniformly.
+// Iterator over the x-runs of the cells at Chebyshev distance d from cell (cx,cy,cz) with r_lo < d <= r_hi
+// (r_lo = -1: the whole cube of radius r_hi), clipped to the grid.  Only the (dz,dy) rows that exist in the grid
+// are enumerated -- a query clamped into a corner of a long thin grid would otherwise walk (2r+1)^2 row slots per
+// ring, almost all of them outside.  The run bounds of up to 64 rows are fetched by the 64 lanes in parallel (one
+// memory round trip per 64 rows instead of two dependent scalar loads per row), rows without points are skipped
+// with a ballot, and the runs are handed out one 64-candidate step at a time, wave-uniformly.
 struct ShellIter {
-    int ring, width, nrows, row, part, pos, end, chunk;
-    bool full;
+    int r_lo, ring, zlo, ylo, wy, nrows, row, part, pos, end, chunk;
+    unsigned long long live;        // rows of the current chunk that hold at least one point
     int b_s0, b_e0, b_s1, b_e1;     // per lane: bounds of the (up to two) runs of row chunk + lane
-    __device__ __forceinline__ void start(int r, bool whole_cube) {
-        ring = r; width = 2 * r + 1; nrows = width * width; row = 0; part = 0; pos = 0; end = 0; chunk = -1;
-        full = whole_cube;
+    __device__ __forceinline__ void start(const pct_grid& g, int cy, int cz, int lo, int hi) {
+        r_lo = lo; ring = hi;
+        zlo = max(-hi, -cz);
+        ylo = max(-hi, -cy);
+        const int zhi = min(hi, g.nz - 1 - cz), yhi = min(hi, g.ny - 1 - cy);
+        wy = yhi - ylo + 1;
+        nrows = (zhi - zlo + 1) * wy;
+        row = 0; part = 0; pos = 0; end = 0; chunk = -1; live = 0ull;
     }
     __device__ __forceinline__ void fetch(const pct_grid& g, const int* __restrict__ cs, int cx, int cy, int cz) {
         const int ri = chunk + lane_id();
         b_s0 = b_e0 = b_s1 = b_e1 = 0;
         if (ri < nrows) {
-            const int dz = ri / width - ring, dy = ri % width - ring;
-            const int z = cz + dz, y = cy + dy;
-            if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-                const int base = (z * g.ny + y) * g.nx;
-                const bool face = full || dz == -ring || dz == ring || dy == -ring || dy == ring;
-                if (face) {
-                    b_s0 = cs[base + max(cx - ring, 0)];
-                    b_e0 = cs[base + min(cx + ring, g.nx - 1) + 1];
-                } else {
-                    if (cx - ring >= 0) { b_s0 = cs[base + cx - ring]; b_e0 = cs[base + cx - ring + 1]; }
-                    if (cx + ring < g.nx) { b_s1 = cs[base + cx + ring]; b_e1 = cs[base + cx + ring + 1]; }
-                }
+            const int dz = zlo + ri / wy, dy = ylo + ri % wy;
+            const int base = ((cz + dz) * g.ny + (cy + dy)) * g.nx;
+            const bool inner = max(abs(dz), abs(dy)) <= r_lo;      // the row crosses the cube already searched
+            if (!inner) {
+                b_s0 = cs[base + max(cx - ring, 0)];
+                b_e0 = cs[base + min(cx + ring, g.nx - 1) + 1];
+            } else {
+                const int a0 = max(cx - ring, 0), a1 = cx - r_lo - 1;        // left of the searched cube
+                const int c0 = cx + r_lo + 1, c1 = min(cx + ring, g.nx - 1); // right of it
+                if (a1 >= a0) { b_s0 = cs[base + a0]; b_e0 = cs[base + a1 + 1]; }
+                if (c1 >= c0) { b_s1 = cs[base + c0]; b_e1 = cs[base + c1 + 1]; }
             }
         }
+        live = __builtin_amdgcn_ballot_w64(b_e0 > b_s0 || b_e1 > b_s1);
     }
     // next 64-candidate step: returns false when the shell is exhausted
     __device__ __forceinline__ bool next(const pct_grid& g, const int* __restrict__ cs, int cx, int cy, int cz, int& base, int& lim) {
         while (pos >= end) {
             if (row >= nrows) return false;
             if (chunk < 0 || row - chunk >= 64) { chunk = row; fetch(g, cs, cx, cy, cz); }
-            const int l = row - chunk;
+            int l = row - chunk;
             if (part == 0) {
+                const unsigned long long rest = live >> l;      // rows of this chunk from l on that hold points
+                if (rest == 0ull) { row = chunk + 64; continue; }
+                const int skip = (int)__builtin_ctzll(rest);
+                row += skip;
+                l += skip;
                 pos = __builtin_amdgcn_readlane(b_s0, l);
                 end = __builtin_amdgcn_readlane(b_e0, l);
                 part = 1;
@@ -419,7 +431,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
         const double gy = (sw.qy - g.oy) * g.inv_cell - cy;
         const double gz = (sw.qz - g.oz) * g.inv_cell - cz;
         ShellIter it;
-        it.start(1, true);
+        it.start(g, cy, cz, -1, 1);
         // candidate loads run one step ahead of their use (a shell is many short runs, each a dependent load)
         int nbase = 0, nlim = 0;
         bool have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
@@ -443,7 +455,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
                 if (lane == 0 && fmin(sw.tau_d, sw.eps2) > limit_r2(g, cx, cy, cz, gx, gy, gz)) atomicAdd(&a.counters[5], 1ull);
                 break;
             }
-            it.start(it.ring + 1, false);
+            // widen: one ring at a time near the query, then by half the radius (a query clamped into a corner of a
+            // large empty grid must not pay one round per ring; the guarantee is that of the outer radius)
+            it.start(g, cy, cz, it.ring, it.ring < 4 ? it.ring + 1 : it.ring + (it.ring + 1) / 2);
             have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
             if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
         }
