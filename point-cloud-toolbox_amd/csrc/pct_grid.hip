@@ -733,14 +733,6 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_TRY(trim_box(ctx, red, bbox));
     }
     const bool sub_box = ctx->level_edge > 0 && ctx->level_box_valid;
-    if (sub_box) {
-        // a fast level pass only needs cells around its owned points: box = their bbox + 2.5 edges (their stencils
-        // end one cell short of the boundary cells, into which every other point is clamped)
-        for (int a = 0; a < 3; ++a) {       // (not intersected with the trimmed box: every owned point must be inside)
-            bbox[a] = ctx->level_box[a] - (float)(2.5 * ctx->level_edge);
-            bbox[3 + a] = ctx->level_box[3 + a] + (float)(2.5 * ctx->level_edge);
-        }
-    }
     const int64_t n = ctx->n_grid;                                        // points the grid holds
     const int g_begin = own_flag ? 0 : (int)ctx->g_begin, g_end = own_flag ? 0 : (int)(ctx->g_begin + n_owned);
 
@@ -788,9 +780,20 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // synchronisation instead of two; a rejected size costs a speculative scatter.
     for (int it = 0; it < max_iter; ++it) {
         if (eps > 0 && a > eps * 1.000001) a = eps * 1.000001;   // one ring already covers the eps ball
+        // sub-box of a fast level pass: 2.5 edges of the FINAL cell size around the owned points (their stencils must
+        // end inside the box: the points outside it are left out of the cell list)
+        const auto set_box = [&]() {
+            if (!sub_box) return;
+            for (int ax = 0; ax < 3; ++ax) {
+                bbox[ax] = ctx->level_box[ax] - (float)(2.5 * a);
+                bbox[3 + ax] = ctx->level_box[3 + ax] + (float)(2.5 * a);
+            }
+        };
+        set_box();
         set_dims(&g, bbox, a);
         while (g.ncell > cell_cap) {
             a *= cbrt((double)g.ncell / (double)cell_cap) * 1.01;
+            set_box();
             set_dims(&g, bbox, a);
         }
         PCT_TRY(pct_reserve(ctx, &ctx->cell_own, (size_t)g.ncell * sizeof(int)));
