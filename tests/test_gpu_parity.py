@@ -647,3 +647,18 @@ def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind):
         i2, d2, c2 = h.get_neighbors(lo, hi, want_count=True)
         assert np.array_equal(i2, ib[lo:hi]) and np.array_equal(d2, db[lo:hi]) and np.array_equal(c2, cb[lo:hi])
         h.close()
+
+
+def test_random_cross_check(gpu):
+    """tools/fuzz_gpu.py for a fixed seed: random clouds (torus, Gaussian at random scale, lattice with ties, blobs of
+    uneven density, shifted egg carton, a line with a far sub-line), random k, eps, dtype, shard -- plain grid sweep,
+    chained sweep and sharded sweep against the exhaustive sweep, bit for bit incl. coefficients and curvatures.  (The
+    same tool run for minutes found the two bugs fixed in the commits that mention it.)"""
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(root, "tools", "fuzz_gpu.py"))
+    fuzz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fuzz)
+    done, bad = fuzz.run(seed0=7, budget=60.0, cases=250, verbose=False)
+    assert bad is None, bad
+    assert done >= 50
