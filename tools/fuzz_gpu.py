@@ -16,7 +16,9 @@ def run(seed0, budget=None, cases=None, verbose=True):
       rng = np.random.default_rng([seed0, it])
       n = int(rng.integers(200, 60_000))
       k = int(rng.integers(1, min(127, n - 1) + 1))
-      kind = rng.integers(0, 6)
+      if rng.random() < 0.2:
+          k = min(int(rng.choice([1, 5, 31, 32, 47, 52, 63, 64, 65, 126, 127])), n - 1)
+      kind = rng.integers(0, 10)
       if kind == 0:
           pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30)))
       elif kind == 1:
@@ -28,9 +30,20 @@ def run(seed0, budget=None, cases=None, verbose=True):
           pts = c[w] + rng.normal(size=(n, 3)) * (10.0 ** rng.uniform(-4, -0.5, size=8))[w, None]
       elif kind == 4:
           pts = shapes.egg_carton_random(n, seed=int(rng.integers(1 << 30))) + rng.uniform(-500, 500, size=3)
-      else:
+      elif kind == 5:
           pts = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1e-3, n), np.zeros(n)], 1)     # nearly a line
           pts[rng.choice(n, max(1, n // 500), replace=False)] += rng.normal(size=3) * 50        # outliers
+      elif kind == 6:                                                                         # exact plane, jittered lattice
+          m = int(np.sqrt(n)) + 1
+          gx, gy = np.meshgrid(np.arange(m), np.arange(m))
+          pts = np.stack([gx.ravel()[:n], gy.ravel()[:n], np.zeros(n)], 1) / m + rng.normal(scale=rng.choice([0, 1e-4, 1e-2]) / m, size=(n, 3)) * [1, 1, 0]
+      elif kind == 7:                                                                         # far from the origin: float32 quantisation
+          pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30))) * 10.0 ** rng.uniform(-2, 1) + 10.0 ** rng.uniform(2, 5)
+      elif kind == 8:                                                                         # two clusters far apart
+          half = n // 2
+          pts = np.vstack([rng.normal(size=(half, 3)) * [1, 1, 0.05], rng.normal(size=(n - half, 3)) * [0.3, 0.3, 0.01] + rng.uniform(20, 2000)])
+      else:                                                                                   # very anisotropic box
+          pts = rng.uniform(0, 1, size=(n, 3)) * [1, 1e-3, 1e-6]
       pts = np.ascontiguousarray(pts, dtype=np.float64 if rng.random() < 0.15 else np.float32)
       eps = 0.0
       if rng.random() < 0.3:
