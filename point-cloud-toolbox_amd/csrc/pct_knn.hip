@@ -705,6 +705,16 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
         m = acc;
     }
     unsigned long long n_flush = 0, n_step = 0, n_redo = 0;
+    // rows of this item that go to the redo list: collected here (bit = query of the item, two bits of reason) and
+    // appended with ONE counter increment when the item is done -- a counter increment per query serialises at the
+    // memory side (~88 per us on one address: 10^5 failing queries of a cloud of uneven density cost a millisecond)
+    unsigned long long redo_mask = 0ull, redo_why_lo = 0ull, redo_why_hi = 0ull;
+    const auto note_redo = [&](int row, int why) {
+        const int q = row - row0;
+        redo_mask |= 1ull << q;
+        redo_why_lo |= (unsigned long long)(why & 1) << q;
+        redo_why_hi |= (unsigned long long)((why >> 1) & 1) << q;
+    };
 
     if (m > CAP) {
         // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
@@ -808,14 +818,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
 
     if constexpr (PRE && PAIR) {
         unsigned short* pend_b = s_pend2[w];
-        const auto push_redo = [&](int row, int why) {
-            if (lane == 0) {
-                const int at = atomicAdd(redo_count, 1);
-                redo[at] = PCT_REDO_ENTRY(row, why);
-                if (a.redo_m) a.redo_m[at] = m;
-            }
-            ++n_redo;
-        };
+        const auto push_redo = [&](int row, int why) { note_redo(row, why); };
         for (int qi = 0; qi < nq; qi += 2) {
             const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
             const int qj = live_b ? qi + 1 : qi;
@@ -1115,12 +1118,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     t = nt;
                 }
                 if (!found || !(T >= 1e-30f)) {                // no usable threshold: the exact sweep takes the query
-                    if (lane == 0) {
-                        const int at = atomicAdd(redo_count, 1);
-                        redo[at] = PCT_REDO_ENTRY(row, 3);
-                        if (a.redo_m) a.redo_m[at] = m;
-                    }
-                    ++n_redo;
+                    note_redo(row, 3);
                     continue;
                 }
                 t_prev_f = T;
@@ -1203,12 +1201,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     t = nt;
                 }
                 if (!found) {                                   // no usable threshold: the exact sweep takes the query
-                    if (lane == 0) {
-                        const int at = atomicAdd(redo_count, 1);
-                        redo[at] = PCT_REDO_ENTRY(row, 3);
-                        if (a.redo_m) a.redo_m[at] = m;
-                    }
-                    ++n_redo;
+                    note_redo(row, 3);
                     continue;
                 }
             }
@@ -1280,12 +1273,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
         }
         if (__ballot(amb) != 0ull) {
-            if (lane == 0) {
-                const int at = atomicAdd(redo_count, 1);
-                redo[at] = PCT_REDO_ENTRY(row, sparse ? 1 : 3);
-                if (a.redo_m) a.redo_m[at] = m;
-            }
-            ++n_redo;
+            note_redo(row, sparse ? 1 : 3);
             continue;
         }
 
@@ -1325,6 +1313,19 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             if (lane == 0) a.nbr_cnt[row] = found;
         }
         if (a.row_done && lane == 0) a.row_done[row] = 1;
+    }
+    if (redo_mask) {
+        const int cnt = (int)__popcll(redo_mask);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(redo_count, cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((redo_mask >> lane) & 1ull) {
+            const int at = base + (int)__popcll(redo_mask & ((1ull << lane) - 1ull));
+            const int why = (int)((redo_why_lo >> lane) & 1ull) | ((int)((redo_why_hi >> lane) & 1ull) << 1);
+            redo[at] = PCT_REDO_ENTRY(row0 + lane, why);
+            if (a.redo_m) a.redo_m[at] = m;
+        }
+        n_redo += (unsigned long long)cnt;
     }
     // statistics are opt-in: ~10^5 waves adding to the same words serialise at the memory side
     if (a.stats && lane == 0) {
