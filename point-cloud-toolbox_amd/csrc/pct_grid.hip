@@ -791,10 +791,12 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         };
         set_box();
         set_dims(&g, bbox, a);
+        bool hit_cap = false;            // the cell budget, not the occupancy target, set this edge
         while (g.ncell > cell_cap) {
             a *= cbrt((double)g.ncell / (double)cell_cap) * 1.01;
             set_box();
             set_dims(&g, bbox, a);
+            hit_cap = true;
         }
         PCT_TRY(pct_reserve(ctx, &ctx->cell_own, (size_t)g.ncell * sizeof(int)));
         PCT_HIP(ctx, hipMemsetAsync(ctx->cell_own.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
@@ -850,7 +852,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         bool eps_bound = eps > 0 && a >= eps;            // cannot grow past eps
         bool capped = g.ncell * 2 > cell_cap && m < target;
         if ((m >= win_lo * target && m <= win_hi * target) || it == max_iter - 1 || (eps_bound && m < target) ||
-            capped || (a >= emax && m < target))
+            capped || (a >= emax && m < target) || (hit_cap && m > target))      // (cannot refine past the cell budget)
             break;
         double d = 2.0;
         if (a_prev > 0 && m != m_prev && a != a_prev) {
