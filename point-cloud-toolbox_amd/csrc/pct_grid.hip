@@ -1,13 +1,16 @@
 // Uniform cell list build for the neighbour sweep (the search structure that
 // stands where the reference builds scipy's cKDTree, pointCloudToolbox.py:74).
 //
-//   pack      xyz (n,3) f32 -> float4 {x,y,z,index}; finite check; bbox partials
+//   pack      xyz (n,3) f32 -> float4 {x,y,z,index}; finite check; bbox and moments per block, folded by a one-block
+//             kernel (sharded handles: k_cull_pack keeps the owned rows and the points near them)
 //   hist      cell id per point + per-cell counts of owned / other points (integer atomics)
 //   occupancy mean points-per-cell as seen by a point (drives the cell size)
 //   scan      exclusive scan of the counts -> cell starts, ordered occupied list
 //   scatter   counting sort of the float4 records into cell order, owned points first in each cell
 //
-// All kernels are HBM/L2 streaming passes over 16 B records with 64-wide waves.
+// All kernels are HBM/L2 streaming passes over 16 B records with 64-wide waves.  Host side (pct_build_grid): outlier-
+// trimmed grid box, cell size by occupancy (warm-started, speculative box from the previous similar cloud), one
+// host synchronisation per accepted build; small results come back through pinned memory the kernels write.
 #include "pct_internal.h"
 
 #include <math.h>

@@ -10,19 +10,18 @@
 //
 // Kernels (all hand-written for gfx950, 64-lane waves):
 //   k_knn_fast   one wave = one work item (a cell and <= 12 of its owned queries).  The 27-cell stencil is staged
-//                once into LDS (12 B per candidate, centre row first, all global loads in flight together), the
-//                item's queries are prefetched into registers; per 64 candidates: fp64 distance, quantised key,
-//                ballot against the running (k+1)-th element, LDS compaction; whenever 64*R survivors are pending a
-//                wave-wide bitonic sort + merge in registers on 32-bit elements (DPP row operations for lane
-//                distances 1,2,4,8, v_permlane16_swap / v_permlane32_swap for 16 and 32: no LDS round trip in the
-//                network).  R = 1 holds k+1 <= 64, R = 2 holds k+1 <= 128.  Anything it cannot prove exact goes
-//                to the redo list.
+//                once into LDS (12 B per candidate, all global loads in flight together), the item's queries are
+//                prefetched into registers.  Per PAIR of queries: float32 squared distances of all staged
+//                candidates in packed arithmetic, a threshold that leaves k+1 .. 64 R of them (ballot counts,
+//                secant steps), compaction of the survivors, exact fp64 keys for those only, ONE wave-wide
+//                bitonic network in registers on 32-bit elements (DPP row operations, v_permlane16/32_swap,
+//                v_med3_u32 compare-exchanges), proof checks, stores.  R = 1 holds k+1 <= 64, R = 2 k+1 <= 128.
+//                Anything it cannot prove exact goes to the redo list (one counter increment per item).
 //   k_knn_exact  one wave = one query of the redo list (or every query, for testing): candidates cube by cube
 //                from global memory, (fp64 d2, public index) comparisons, shell-by-shell widening until the
 //                searched cube guarantees the answer.
 //   k_knn_brute  exhaustive sweep, wave per query: small clouds and the on-device cross-check.
 //   k_export*    neighbour table (sorted space, owned rows) -> public (rows, k) index / distance arrays.
-// Each kernel has ONE candidate step and ONE flush site so that it stays small enough for the I-cache.
 #include "pct_internal.h"
 
 #include <math.h>
@@ -471,20 +470,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
 // Fast sweep: wave = work item (one cell, <= items_q consecutive queries).
 //
 // Elements of the wave-wide network are single 32-bit integers
-//     key << SLOT_BITS | slot
-// slot = LDS slot of a staged stencil candidate; key = floor(d2 * scale) with the
-// exact fp64 squared distance d2 and scale = 2^KEY_BITS / (12.1 cell^2), the
-// largest squared distance the 27-cell stencil can hold.  The quantisation is a
-// monotone map of the exact value, so wherever two keys differ the order is the
-// exact order.  Every situation in which a key collision could influence the k+1
-// smallest (a rejected or dropped candidate sharing the threshold's key, equal
-// neighbours in the final list) raises a flag; flagged queries -- and queries
-// whose answer is not guaranteed to lie inside the stencil, and whole items
-// whose stencil does not fit the LDS staging area -- are appended to the redo
-// list and done by k_knn_exact.  Unflagged results are therefore bit-identical
-// to the exact path: the stored distance is recomputed in fp64 from the
-// coordinates.  One compare-exchange level costs one DPP move (or one
-// v_permlane swap), one 32-bit compare, one scalar mask op and one select.
+//     key << SLOT_BITS | payload
+// payload = LDS slot of a staged stencil candidate (or, on the pre-selection path, the candidate's place in the
+// compacted list of survivors, from which the slot is looked up afterwards); key = floor(d2 * scale) with the
+// exact fp64 squared distance d2 and scale = 2^KEY_BITS / (12.1 cell^2), the largest squared distance the
+// 27-cell stencil can hold.  The quantisation is a monotone map of the exact value, so wherever two keys differ
+// the order is the exact order.  Every situation in which a key collision could influence the k+1 smallest
+// (equal neighbours among the first k+2 of the sorted selection, a saturated key), every query whose answer is
+// not guaranteed to lie inside the stencil or inside what the float32 pre-selection kept, and whole items whose
+// stencil does not fit the LDS staging area are appended to the redo list and done by k_knn_exact.  Unflagged
+// results are therefore bit-identical to the exact path: the stored distance is recomputed in fp64 from the
+// coordinates.  (DESIGN.md 4.2 walks through the steps.)
 // ---------------------------------------------------------------------------
 constexpr unsigned kPadElem = 0xFFFFFFFFu;
 
