@@ -709,7 +709,12 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     const double factor = ctx->occupancy_factor > 0 ? ctx->occupancy_factor : pct_default_factor(k);
     const double target = factor * (k + 1);
     // (the first pass of a chained sweep only has to be roughly right: the later passes adapt)
-    const int64_t cell_cap = (int64_t)1 << (ctx->level_mode ? 24 : 27);
+    // cell budget: 2^27 cells (1.6 GB of counters and starts) serve surfaces of up to a few million points; beyond,
+    // 32 cells per point up to 2^30 (a 60 M-point torus wants 3.3e8 cells: capped at 2^27 its cells held 51 points
+    // instead of 29.5, the staging area overflowed and the sweep took 235 ms instead of ~40)
+    int64_t cell_cap = (int64_t)1 << 27;
+    if (ctx->level_mode) cell_cap = (int64_t)1 << 24;
+    else if (32 * ctx->n > cell_cap) cell_cap = 32 * ctx->n < ((int64_t)1 << 30) ? 32 * ctx->n : (int64_t)1 << 30;
     const float* own_flag = (const float*)ctx->own_flag;   // level passes: ownership by wanted-edge band
     const int64_t n_owned = own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
     const bool sharded = own_flag || ctx->q_begin > 0 || ctx->q_end < ctx->n;   // some points are candidates only
