@@ -13,6 +13,8 @@ t0 = time.time(); pts = shapes.torus_random(n, seed=77); print(f"generated {n} p
 h = _capi.Handle(0)
 h.set_points(pts)
 h.curvature(k, 0.0, _capi.KNN_GRID)
+print("cold call:", {kk: round(v, 1) for kk, v in h.timings().items() if kk in ("grid_ms", "knn_ms", "fit_ms", "total_ms")}, flush=True)
+h.curvature(k, 0.0, _capi.KNN_GRID)
 t = h.timings()
 print({kk: (round(v, 3) if isinstance(v, float) else v) for kk, v in t.items() if kk in ("grid_ms", "knn_ms", "fit_ms", "total_ms", "cells", "occupied_cells", "occupancy")}, flush=True)
 rng = np.random.default_rng(1)
