@@ -55,9 +55,25 @@ def cpu_baseline(pts, k, seconds_target=15.0):
     t0 = time.perf_counter()
     _run_loop(oracle, tree, pts, rows, k)
     dt = time.perf_counter() - t0
-    return {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
-            "sample": f"{m} random rows of the same {n}-point torus, k={k}, per-point loop "
-                      f"(cKDTree.query + cov/svd + lstsq, oracle/pct_oracle.py), tree build excluded, {dt:.1f} s"}
+    out = {"value": m / dt, "unit": "points/s", "cores": 1, "kind": "port",
+           "sample": f"{m} random rows of the same {n}-point torus, k={k}, per-point loop "
+                     f"(cKDTree.query + cov/svd + lstsq, oracle/pct_oracle.py), tree build excluded, {dt:.1f} s"}
+    # the vectorised restatement on every host core (threaded cKDTree.query + batched eigh / solve)
+    try:
+        mb = int(min(n, 40_000))
+        t0 = time.perf_counter()
+        oracle.pipeline_batched(pts, k, rows=np.sort(rng.choice(n, mb, replace=False)), workers=-1, tree=tree)
+        rate_b = mb / (time.perf_counter() - t0)
+        mb = int(min(n, max(mb, rate_b * 10.0)))                  # about 10 s of work
+        rows_b = np.sort(rng.choice(n, mb, replace=False))
+        t0 = time.perf_counter()
+        oracle.pipeline_batched(pts, k, rows=rows_b, workers=-1, tree=tree)
+        dtb = time.perf_counter() - t0
+        out["all_cores"] = {"value": mb / dtb, "unit": "points/s", "cores": os.cpu_count(),
+                            "sample": f"{mb} random rows, vectorised restatement (oracle.pipeline_batched), {dtb:.1f} s"}
+    except Exception as e:      # the headline baseline above stands on its own
+        out["all_cores"] = {"error": str(e)[:200]}
+    return out
 
 
 def _run_loop(oracle, tree, pts, rows, k):
