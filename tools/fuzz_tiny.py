@@ -1,0 +1,29 @@
+"""Tiny clouds (2..300 points): grid and chained sweeps against the exhaustive one (developer tool)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import __graft_entry__ as ge
+ge.build()
+from point_cloud_toolbox_amd import _capi
+t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
+it = 0
+while time.time() < t_end:
+    rng = np.random.default_rng([9, it])
+    n = int(rng.integers(2, 300)); k = int(rng.integers(1, min(127, n - 1) + 1))
+    kind = rng.integers(0, 4)
+    pts = (rng.normal(size=(n, 3)) if kind == 0 else rng.uniform(0, 1, (n, 3)) * [1, 1, 0] if kind == 1
+           else np.round(rng.uniform(0, 3, (n, 3))) if kind == 2 else np.repeat(rng.normal(size=(1, 3)), n, 0) + rng.normal(size=(n, 3)) * 1e-7)
+    pts = np.ascontiguousarray(pts, dtype=np.float32 if rng.random() < 0.8 else np.float64)
+    eps = float(rng.uniform(0.05, 2)) if rng.random() < 0.3 else 0.0
+    h = _capi.Handle(0); h.set_points(pts)
+    h.curvature(k, eps, _capi.KNN_BRUTE)
+    ib, db, cb = h.get_neighbors(0, n, want_count=True); cfb, Kb, Hb, _ = h.get_fit(0, n)
+    for algo in (_capi.KNN_GRID, _capi.KNN_GRID_LEVELS, _capi.KNN_GRID_EXACT):
+        h.curvature(k, eps, algo)
+        ig, dg, cg = h.get_neighbors(0, n, want_count=True); cfg, Kg, Hg, _ = h.get_fit(0, n)
+        if not (np.array_equal(ib, ig) and np.array_equal(db, dg) and np.array_equal(cb, cg) and np.array_equal(cfb, cfg, equal_nan=True)
+                and np.array_equal(Kb, Kg, equal_nan=True)):
+            print("MISMATCH", it, n, k, kind, eps, pts.dtype, "algo", algo); sys.exit(1)
+    h.close(); it += 1
+print("tiny fuzz ok:", it)
