@@ -692,9 +692,17 @@ static void set_dims(pct_grid* g, const float* bbox, double a) {
     g->cell = a;
     g->inv_cell = 1.0 / a;
     double ex = (double)bbox[3] - bbox[0], ey = (double)bbox[4] - bbox[1], ez = (double)bbox[5] - bbox[2];
-    g->nx = (int32_t)floor(ex * g->inv_cell) + 1;
-    g->ny = (int32_t)floor(ey * g->inv_cell) + 1;
-    g->nz = (int32_t)floor(ez * g->inv_cell) + 1;
+    // counted in double first: an absurdly small edge (eps = 1e-30) must read as "far too many cells" for the caller's
+    // budget loop, not overflow the int32 dimensions
+    const double dx = floor(ex * g->inv_cell) + 1, dy = floor(ey * g->inv_cell) + 1, dz = floor(ez * g->inv_cell) + 1;
+    if (!(dx * dy * dz < 4.0e18) || !(dx < 2.0e9) || !(dy < 2.0e9) || !(dz < 2.0e9)) {
+        g->nx = g->ny = g->nz = 1 << 30;
+        g->ncell = (int64_t)1 << 62;
+        return;
+    }
+    g->nx = (int32_t)dx;
+    g->ny = (int32_t)dy;
+    g->nz = (int32_t)dz;
     g->ncell = (int64_t)g->nx * g->ny * g->nz;
 }
 

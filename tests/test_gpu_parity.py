@@ -662,3 +662,48 @@ def test_random_cross_check(gpu):
     done, bad = fuzz.run(seed0=7, budget=60.0, cases=250, verbose=False)
     assert bad is None, bad
     assert done >= 50
+
+
+def test_edge_calls(gpu):
+    """Degenerate requests end in the reference's exceptions or in well-defined results, never in a crash."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(5000, seed=3)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    for bad_k in (0, 128):
+        with pytest.raises(ValueError):
+            h.knn(bad_k)
+    h.knn(10, eps=-1.0)                                            # a non-positive eps means "no bound"
+    h.set_query_range(100, 100)                                    # an empty owned range is legal
+    h.curvature(10, 0.0, capi.KNN_GRID)
+    assert h.get_fit(100, 100)[1].shape == (0,)
+    h.set_query_range(100, 101)
+    h.curvature(10, 0.0, capi.KNN_GRID)
+    one = h.get_fit(100, 101)[1]
+    with pytest.raises(ValueError):
+        h.set_query_range(10, 5)
+    h.set_query_range(0, 5000)
+    h.curvature(10, 0.0, capi.KNN_GRID)
+    assert h.get_fit(100, 101)[1] == one
+    h.curvature(10, 1e30, capi.KNN_GRID)                           # an eps ball that holds the cloud
+    assert np.array_equal(h.get_fit(100, 101)[1], one)
+    h.curvature(10, 1e-30, capi.KNN_GRID)                          # ... and one that holds nothing
+    _, _, cnt = h.get_neighbors(0, 5000, want_count=True)
+    assert (cnt == 0).all() and np.isnan(h.get_fit(0, 5000)[1]).all()
+    h.set_points(pts[:100])
+    with pytest.raises(AttributeError):
+        h.fit()                                                    # no table for the new cloud yet
+    with pytest.raises(IndexError):
+        h.knn(100)                                                 # k + 1 > N
+    h.set_points(pts[:2])
+    h.curvature(1, 0.0, capi.KNN_GRID)
+    assert np.array_equal(h.get_neighbors(0, 2)[0].ravel(), [1, 0])
+    h.set_points(np.zeros((500, 3), np.float32))                   # all points identical: ties by index
+    h.curvature(20, 0.0, capi.KNN_GRID)
+    assert np.array_equal(h.get_neighbors(0, 1)[0][0], np.arange(1, 21))
+    with pytest.raises(ValueError):
+        h.set_points(np.vstack([pts[:100], [[np.inf, 0, 0]]]).astype(np.float32))
+        h.knn(5)
+    h.close()
+    with pytest.raises(ValueError):
+        h.knn(5)
