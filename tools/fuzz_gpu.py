@@ -18,7 +18,7 @@ def run(seed0, budget=None, cases=None, verbose=True):
       k = int(rng.integers(1, min(127, n - 1) + 1))
       if rng.random() < 0.2:
           k = min(int(rng.choice([1, 5, 31, 32, 47, 52, 63, 64, 65, 126, 127])), n - 1)
-      kind = rng.integers(0, 10)
+      kind = rng.integers(0, 11)
       if kind == 0:
           pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30)))
       elif kind == 1:
@@ -42,8 +42,10 @@ def run(seed0, budget=None, cases=None, verbose=True):
       elif kind == 8:                                                                         # two clusters far apart
           half = n // 2
           pts = np.vstack([rng.normal(size=(half, 3)) * [1, 1, 0.05], rng.normal(size=(n - half, 3)) * [0.3, 0.3, 0.01] + rng.uniform(20, 2000)])
-      else:                                                                                   # very anisotropic box
+      elif kind == 9:                                                                         # very anisotropic box
           pts = rng.uniform(0, 1, size=(n, 3)) * [1, 1e-3, 1e-6]
+      else:                                                                                   # extreme magnitudes (float32 squares overflow / underflow)
+          pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30))).astype(np.float64) * 10.0 ** rng.choice([-30, -22, -15, 12, 18, 25, 30])
       pts = np.ascontiguousarray(pts, dtype=np.float64 if rng.random() < 0.15 else np.float32)
       eps = 0.0
       if rng.random() < 0.3:
