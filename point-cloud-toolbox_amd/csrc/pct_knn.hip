@@ -1485,7 +1485,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
         const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
         const int2* items = (const int2*)ctx->occ.p;
-        const bool e = eps > 0, pre = !ctx->has_f64, r1 = k + 1 <= pct_fast_r1_max();
+        // The float32 pre-selection squares coordinate differences of up to three cell edges: outside this window
+        // they overflow (or the eps ball's radius underflows) and every candidate would fail the threshold test,
+        // so such clouds take the variant that keys every candidate in float64.
+        const double c2 = ctx->grid.cell * ctx->grid.cell;
+        const bool f32_ok = c2 > 1e-30 && c2 < 1e30 && (!(eps > 0) || eps * eps > 1e-36);
+        const bool e = eps > 0, pre = !ctx->has_f64 && f32_ok, r1 = k + 1 <= pct_fast_r1_max();
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         static const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;          // tuning aid

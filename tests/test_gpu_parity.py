@@ -706,4 +706,25 @@ def test_edge_calls(gpu):
         h.knn(5)
     h.close()
     with pytest.raises(ValueError):
-        h.knn(5)
+        h.knn(5)@pytest.mark.gpu
+@pytest.mark.parametrize("scale", [1e-30, 1e-15, 1e18, 1e25])
+def test_coordinates_whose_squares_leave_float32(gpu, scale):
+    """Coordinate differences whose squares overflow or underflow float32 still give the exhaustive sweep's table,
+    with and without an eps ball (the float32 pre-selection must step aside, not drop every candidate)."""
+    capi = gpu["capi"]
+    pts = (gpu["shapes"].torus_random(20000, seed=5).astype(np.float64) * scale).astype(np.float32)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    for k, eps in ((30, 0.0), (92, 0.07 * scale), (12, 0.01 * scale)):
+        h.curvature(k, eps, capi.KNN_BRUTE)
+        want = h.get_neighbors(0, 20000, want_count=True) + (h.get_fit(0, 20000)[0],)
+        h.curvature(k, eps, capi.KNN_GRID)
+        got = h.get_neighbors(0, 20000, want_count=True) + (h.get_fit(0, 20000)[0],)
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g, equal_nan=True)
+        if eps > 0:
+            assert want[2].max() > 0
+    h.close()
+
+
+

@@ -2,27 +2,14 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
 import __graft_entry__ as ge
 ge.build()
-from point_cloud_toolbox_amd import _capi, shapes
+from point_cloud_toolbox_amd import _capi
+from fuzz_gpu import make_case
 seed0, it = int(sys.argv[1]), int(sys.argv[2])
-rng = np.random.default_rng([seed0, it])
-n = int(rng.integers(200, 60_000)); k = int(rng.integers(1, min(127, n - 1) + 1)); kind = rng.integers(0, 6)
-if kind == 0: pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30)))
-elif kind == 1: pts = rng.normal(size=(n, 3)) * 10.0 ** rng.uniform(-3, 3)
-elif kind == 2: pts = np.round(rng.uniform(-1, 1, size=(n, 3)) * rng.integers(3, 200)) / 16.0
-elif kind == 3:
-    c = rng.uniform(-1, 1, size=(8, 3)); w = rng.integers(0, 8, size=n)
-    pts = c[w] + rng.normal(size=(n, 3)) * (10.0 ** rng.uniform(-4, -0.5, size=8))[w, None]
-elif kind == 4: pts = shapes.egg_carton_random(n, seed=int(rng.integers(1 << 30))) + rng.uniform(-500, 500, size=3)
-else:
-    pts = np.stack([rng.uniform(0, 1, n), rng.uniform(0, 1e-3, n), np.zeros(n)], 1)
-    pts[rng.choice(n, max(1, n // 500), replace=False)] += rng.normal(size=3) * 50
-pts = np.ascontiguousarray(pts, dtype=np.float64 if rng.random() < 0.15 else np.float32)
-eps = 0.0
-if rng.random() < 0.3:
-    ext = float(np.ptp(pts, axis=0).max()); eps = ext * 10.0 ** rng.uniform(-2.5, -0.5)
+rng, pts, n, k, kind, eps = make_case(seed0, it)
 print("case", n, k, kind, eps, pts.dtype)
 h = _capi.Handle(0); h.set_points(pts)
 h.curvature(k, eps, _capi.KNN_BRUTE)
