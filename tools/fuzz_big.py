@@ -26,6 +26,9 @@ while time.time() < t_end:
     else:
         xy = rng.uniform(-1, 1, size=(n, 2)) * rng.uniform(0.2, 1.0, size=(n, 1)) ** 2
         pts = np.stack([xy[:, 0], xy[:, 1], 0.1 * np.sin(4 * xy[:, 0])], 1)      # density falls off outwards
+    if rng.random() < 0.12:                                        # magnitudes whose squares leave float32
+        pts = pts.astype(np.float64) * 10.0 ** rng.choice([-28, -17, 14, 21, 29])
+        kind += 10
     pts = np.ascontiguousarray(pts, dtype=np.float32)
     eps = 0.0
     if rng.random() < 0.25:

@@ -16,6 +16,8 @@ while time.time() < t_end:
            else np.round(rng.uniform(0, 3, (n, 3))) if kind == 2 else np.repeat(rng.normal(size=(1, 3)), n, 0) + rng.normal(size=(n, 3)) * 1e-7)
     pts = np.ascontiguousarray(pts, dtype=np.float32 if rng.random() < 0.8 else np.float64)
     eps = float(rng.uniform(0.05, 2)) if rng.random() < 0.3 else 0.0
+    if rng.random() < 0.2:                                         # magnitudes whose squares leave float32
+        mag = 10.0 ** rng.uniform(-30, 30); pts = (pts.astype(np.float64) * mag).astype(pts.dtype); eps *= mag
     h = _capi.Handle(0); h.set_points(pts)
     h.curvature(k, eps, _capi.KNN_BRUTE)
     ib, db, cb = h.get_neighbors(0, n, want_count=True); cfb, Kb, Hb, _ = h.get_fit(0, n)
