@@ -728,3 +728,42 @@ def test_coordinates_whose_squares_leave_float32(gpu, scale):
 
 
 
+
+
+@pytest.mark.gpu
+def test_handles_are_independent_across_threads(gpu):
+    """no global mutable state -- several handles driven from different host threads at once (ctypes drops
+    the GIL during a call) give exactly what each gives alone."""
+    import threading
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    jobs = [(shapes.torus_random(60_000, seed=11), 50, 0.0), (shapes.egg_carton_random(45_000, seed=12), 30, 0.0),
+            (shapes.fibonacci_sphere(30_000), 80, 0.05), (shapes.torus_random(52_000, seed=13).astype(np.float64), 20, 0.0)]
+
+    def run(job, rounds, out):
+        pts, k, eps = job
+        h = capi.Handle(0)
+        try:
+            for _ in range(rounds):
+                h.set_points(pts)
+                h.curvature(k, eps, capi.KNN_GRID)
+                out.append(h.get_neighbors(0, len(pts), want_count=True) + h.get_fit(0, len(pts))[:3])
+        except Exception as e:          # surfaced by the assert below
+            out.append(e)
+        finally:
+            h.close()
+
+    alone = []
+    for job in jobs:
+        res = []
+        run(job, 1, res)
+        alone.append(res[0])
+    together = [[] for _ in jobs]
+    threads = [threading.Thread(target=run, args=(job, 6, together[i])) for i, job in enumerate(jobs)]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    for want, got in zip(alone, together):
+        assert len(got) == 6
+        for res in got:
+            assert not isinstance(res, Exception), res
+            for w, g in zip(want, res):
+                assert np.array_equal(w, g, equal_nan=True)
