@@ -654,14 +654,31 @@ def test_random_cross_check(gpu):
     uneven density, shifted egg carton, a line with a far sub-line), random k, eps, dtype, shard -- plain grid sweep,
     chained sweep and sharded sweep against the exhaustive sweep, bit for bit incl. coefficients and curvatures.  (The
     same tool run for minutes found the two bugs fixed in the commits that mention it.)"""
-    import importlib.util, os
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    spec = importlib.util.spec_from_file_location("fuzz_gpu", os.path.join(root, "tools", "fuzz_gpu.py"))
-    fuzz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fuzz)
-    done, bad = fuzz.run(seed0=7, budget=60.0, cases=250, verbose=False)
+    done, bad = _tool("fuzz_gpu").run(seed0=7, budget=60.0, cases=250, verbose=False)
     assert bad is None, bad
     assert done >= 50
+
+
+def _tool(name):
+    import importlib.util, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.gpu
+def test_random_cross_check_large_and_tiny(gpu):
+    """Fixed-seed slices of tools/fuzz_big.py (0.1 .. 0.5 M points: fast sweep + redo against the all-exact sweep of the
+    same cell list, whole cloud and one random shard) and tools/fuzz_tiny.py (2 .. 300 points: grid, chained and
+    all-exact sweeps against the exhaustive one), bit for bit."""
+    done, bad = _tool("fuzz_big").run(seed0=11, budget=40.0, cases=10, verbose=False, n_max_log10=5.7)
+    assert bad is None, bad
+    assert done >= 3
+    done, bad = _tool("fuzz_tiny").run(seed0=13, budget=30.0, cases=300)
+    assert bad is None, bad
+    assert done >= 100
 
 
 def test_edge_calls(gpu):
