@@ -920,6 +920,16 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             if (!live_b) { T_b = 0.f; cnt_b = 0; }
             // ---- compact the slots of the survivors of both queries, then exact keys for them only ------------------
             FastK<2 * R> both;                 // set 0 = query a (registers 0 .. R-1), set 1 = query b
+            float out_d[2 * R];                // float32 distance / sorted position of survivor lane + 64 r of each set
+            int out_p[2 * R];
+            const auto slot_to_pos = [&](int j) {
+                unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+                if constexpr ((CAP / 64 + 7) / 8 > 1) {
+                    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
+                    code = (j >> 9) ? hi : code;
+                }
+                return j + offc[(code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u];
+            };
             {
                 int base_a = 0, base_b = 0;
                 wave_lds_sync();
@@ -936,20 +946,27 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 }
                 wave_lds_sync();
                 const double qax = (double)ax, qay = (double)ay, qaz = (double)az, qbx = (double)bx, qby = (double)by, qbz = (double)bz;
+                // Survivor i's exact distance and sorted position are worked out here, by the lane that holds its
+                // coordinates anyway, and parked in that lane (out_d / out_p); after the sort the lane that ends up
+                // with list entry i fetches them with one cross-lane read each instead of recomputing them.
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int i = lane + 64 * r;
                     unsigned e_a = kPadElem, e_b = kPadElem;
+                    const int ja = (int)pend[i] & (CAP_POW2 - 1), jb = (int)pend_b[i] & (CAP_POW2 - 1);   // stale beyond cnt: masked, unused
+                    out_p[r] = slot_to_pos(ja);           // cross-lane reads inside: every lane active here
+                    out_p[R + r] = slot_to_pos(jb);
+                    out_d[r] = out_d[R + r] = INFINITY;
                     if (i < cnt_a) {
-                        const int j = (int)pend[i];
-                        const double dx = (double)cand_x[j] - qax, dy = (double)cand_y[j] - qay, dz = (double)cand_z[j] - qaz;
+                        const double dx = (double)cand_x[ja] - qax, dy = (double)cand_y[ja] - qay, dz = (double)cand_z[ja] - qaz;
                         const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        out_d[r] = (float)sqrt(d2);
                         if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
                     }
                     if (i < cnt_b) {
-                        const int j = (int)pend_b[i];
-                        const double dx = (double)cand_x[j] - qbx, dy = (double)cand_y[j] - qby, dz = (double)cand_z[j] - qbz;
+                        const double dx = (double)cand_x[jb] - qbx, dy = (double)cand_y[jb] - qby, dz = (double)cand_z[jb] - qbz;
                         const double d2 = (dx * dx + dy * dy) + dz * dz;
+                        out_d[R + r] = (float)sqrt(d2);
                         if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
                     }
                     both.e[r] = e_a;
@@ -1007,31 +1024,26 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 const bool ok = set == 0 ? ok_a : ok_b;
                 const int row = set == 0 ? row_a : row_b;
                 int found = 0;
+                char* const prow = (char*)(a.nbr_pos + (int64_t)row * a.pitch);      // uniform: scalar base + lane offset
+                char* const drow = (char*)(a.nbr_dist + (int64_t)row * a.pitch);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const int i = lane + 64 * r;
                     const unsigned e = both.e[set * R + r];
                     const bool real = e != kPadElem;
-                    const unsigned at = e & ((1u << SLOT_BITS) - 1u);
-                    const int j = (set == 0 ? (int)pend[at] : (int)pend_b[at]) & (CAP_POW2 - 1);
-                    unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
-                    if constexpr ((CAP / 64 + 7) / 8 > 1) {
-                        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
-                        code = (j >> 9) ? hi : code;
+                    const unsigned at = e & ((1u << SLOT_BITS) - 1u);       // survivor index: lane at & 63, register at >> 6
+                    float dist = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R])));
+                    int pos = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
+#pragma unroll
+                    for (int r2 = 1; r2 < R; ++r2) {
+                        const float d2nd = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R + r2])));
+                        const int p2nd = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
+                        if ((int)(at >> 6) == r2) { dist = d2nd; pos = p2nd; }
                     }
-                    const unsigned t = (code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u;
-                    const int pos_real = j + offc[t];
                     if (ok && i >= 1 && i <= k) {
-                        int pos = -1;
-                        float dist = INFINITY;
-                        if (real) {
-                            const double qx = (double)(set == 0 ? ax : bx), qy = (double)(set == 0 ? ay : by), qz = (double)(set == 0 ? az : bz);
-                            const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
-                            dist = (float)sqrt((dx * dx + dy * dy) + dz * dz);
-                            pos = pos_real;
-                        }
-                        a.nbr_pos[(int64_t)row * a.pitch + (i - 1)] = pos;
-                        a.nbr_dist[(int64_t)row * a.pitch + (i - 1)] = dist;
+                        const unsigned off = (unsigned)(i - 1) * 4u;
+                        *(int*)(prow + off) = real ? pos : -1;
+                        *(float*)(drow + off) = real ? dist : INFINITY;
                         found += real;
                     }
                 }

@@ -1,4 +1,5 @@
-# A/B of build flags on one box: tools/ab.sh "<flags A>" "<flags B>" ...
+# A/B of build flags on one box: tools/ab.sh "<flags A>" "<flags B>" ...   (each variant is compiled on the box)
 for v in "$@"; do
-  echo "[$v]"; PCT_EXTRA_FLAGS="$v" timeout -k 10 400 python tools/tune_factor.py 1000000 50 0.55 0.55 | cut -c1-72
+  echo "[$v]"
+  PCT_EXTRA_FLAGS="$v" timeout -k 10 400 python bench.py --no-cpu-baseline --steps 40 --warmup 5 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(round(d['ms_per_step'],4), {k: round(v,4) for k,v in d['stage_ms'].items()})"
 done
