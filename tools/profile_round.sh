@@ -1,7 +1,8 @@
+# developer tool: every profile artefact of one build from one box: bash tools/profile_round.sh <tag>  ->  gpurun_out/prof_<tag>/
 set -e
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-O=gpurun_out/prof_m
+O=gpurun_out/prof_${1:-x}
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 echo bench done
