@@ -135,6 +135,17 @@ int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end,
 int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t rows,
                                      float* K, float* H, float* H2);
 
+/* self.kdtree.query(x, k[, distance_upper_bound=eps]) (the reference's tree object, pointCloudToolbox.py:74; called
+ * with arbitrary points at pct:625, 759, 844): the k nearest CLOUD points of each of m caller-supplied float64 query
+ * points -- nothing is dropped (a query that coincides with a cloud point gets that point first, distance 0).
+ * The cloud is the float32-rounded one the tree is built from (pct:74); squared distances are accumulated in float64
+ * as ((dx^2 + dy^2) + dz^2), rows ascending, exact ties by index.  idx (m,k) int32, dist (m,k) float64; missing
+ * entries (k > N, or beyond eps when eps > 0): index N and +inf, as SciPy pads.  1 <= k <= 128.
+ * Exhaustive sweep, one wave per query: meant for the hundreds of sample points of the neighbour study, not for
+ * the per-point loop (that is pct_knn). */
+int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, double eps,
+                     int32_t* idx, double* dist);
+
 /* explicit_quadratic_neighbor_study (pct:732-800), the numeric part: for every sample row s and every
  * neighbour count n in [n_lo, n_hi], the Gaussian curvature of the quadric fitted to the point itself plus
  * its n nearest neighbours (pct:759-761).  Needs a resident plain k-NN table with k >= n_hi.

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pct_get_fit": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p, _f32p]),
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
+    "pct_query_points": (C.c_int, [_p, _f64p, C.c_int64, C.c_int32, C.c_double, _i32p, _f64p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
     "pct_voxel_downsample": (C.c_int, [_p, _f64p, C.c_int64, C.c_double, _i64p, _i64p]),
     "pct_surface_variation": (C.c_int, [_p, C.c_int32, _f32p]),
@@ -245,6 +246,16 @@ class Handle:
         self._check(self._lib.pct_get_neighbors(self._h, int(begin), int(end), _ptr(idx, _i32p),
                                                 _ptr(dist, _f32p), _ptr(cnt, _i32p)))
         return idx, dist, cnt
+
+    def query_points(self, q, k, eps=0.0):
+        """The reference tree's ``query`` for arbitrary points: (m,3) float64 -> idx (m,k) int32 (missing: N), dist (m,k) float64 (missing: inf)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        if q.ndim != 2 or q.shape[1] != 3:
+            raise ValueError("query points must have shape (m, 3)")
+        idx = np.empty((len(q), int(k)), np.int32)
+        dist = np.empty((len(q), int(k)), np.float64)
+        self._check(self._lib.pct_query_points(self._h, _ptr(q, _f64p), len(q), int(k), float(eps or 0.0), _ptr(idx, _i32p), _ptr(dist, _f64p)))
+        return idx, dist
 
     def get_neighbor_rows(self, rows):
         rows = np.ascontiguousarray(rows, dtype=np.int64)

@@ -92,7 +92,7 @@ void pct_destroy(pct_ctx* ctx) {
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
                       &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
-                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt};
+                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4};
     for (pct_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
@@ -115,7 +115,7 @@ static int new_cloud(pct_ctx* ctx, int64_t n) {
     ctx->n = n;
     ctx->q_begin = 0;
     ctx->q_end = n;
-    ctx->grid_valid = ctx->knn_valid = ctx->fit_valid = ctx->pts4_valid = false;
+    ctx->grid_valid = ctx->knn_valid = ctx->fit_valid = ctx->pts4_valid = ctx->qpts4_valid = false;
     ctx->has_f64 = false;
     ctx->no_cull = ctx->culled = false;
     ctx->retries = 0;
@@ -417,6 +417,26 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     ctx->fit_row_order = false;
     ctx->fit_valid = true;
     ctx->knn_valid = false;   // results are row-aligned now, not cloud-aligned
+    return PCT_OK;
+}
+
+int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, double eps, int32_t* idx, double* dist) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->n <= 0 || !ctx->xyz_view) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
+    if (m < 0 || (m > 0 && (!q_xyz || !idx || !dist))) return pct_fail(ctx, PCT_ERR_INVALID, "bad query arrays");
+    if (k < 1 || k > 128) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,128]", k);
+    if (m == 0) return PCT_OK;
+    for (int64_t i = 0; i < 3 * m; ++i)
+        if (!isfinite(q_xyz[i])) return pct_fail(ctx, PCT_ERR_NONFINITE, "query point %lld is not finite", (long long)(i / 3));
+    if (!(eps >= 0) || isinf(eps)) eps = 0;
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)m * 3 * sizeof(double)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)m * k * sizeof(int32_t)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_c, (size_t)m * k * sizeof(double)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, q_xyz, (size_t)m * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_launch_query_points(ctx, (const double*)ctx->stage_a.p, m, k, eps, (int32_t*)ctx->stage_b.p, (double*)ctx->stage_c.p));
+    PCT_HIP(ctx, hipMemcpyAsync(idx, ctx->stage_b.p, (size_t)m * k * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(dist, ctx->stage_c.p, (size_t)m * k * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCT_OK;
 }
 

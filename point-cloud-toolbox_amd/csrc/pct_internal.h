@@ -126,6 +126,8 @@ struct pct_ctx {
 
     // staging for downloads / host-index fits
     pct_buf stage_a, stage_b, stage_c, stage_d;
+    pct_buf qpts4;      // float4 {x,y,z,index} of EVERY point in public order, for pct_query_points (built on first use)
+    bool qpts4_valid = false;
 
     pct_timings tm = {};
 };
@@ -191,6 +193,7 @@ int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samp
 int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
+int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t k, double eps, int32_t* d_idx, double* d_dist);
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt);
 int pct_launch_mesh_energies(pct_ctx* ctx, const double* d_v, const int* d_tri, int64_t n_tri, const void* d_K, const void* d_H,

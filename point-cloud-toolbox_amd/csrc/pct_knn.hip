@@ -1388,6 +1388,55 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_brute(KnnArgs a) {
     sw.store(q - a.q_begin, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
 }
 
+// cKDTree.query for caller-supplied points (pct_query_points): the exhaustive sweep with the query read from a
+// separate array and every element of the list stored (nothing is "the point itself" here).
+__global__ __launch_bounds__(256) void k_plain_records(const float* __restrict__ xyz, int64_t n, float4* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float((int)i));
+}
+
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_query_points(const float4* __restrict__ pts, int n, const double* __restrict__ q_xyz,
+                                                                      int64_t m, int k, double eps2, int* __restrict__ idx_out,
+                                                                      double* __restrict__ dist_out) {
+    __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
+    __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int64_t q = (int64_t)blockIdx.x * kWavesPerBlock + w;
+    if (q >= m) return;
+    Sweep<R> sw;
+    sw.k = k - 1;                        // the list keeps elements 0 .. sw.k: the k nearest
+    sw.eps2 = eps2;
+    sw.pts = pts;
+    sw.pend_d = s_pend_d[w];
+    sw.pend_p = s_pend_p[w];
+    sw.qx = q_xyz[3 * q]; sw.qy = q_xyz[3 * q + 1]; sw.qz = q_xyz[3 * q + 2];
+    sw.reset();
+    for (int base = 0;; base += 64) {
+        const bool have = base < n;
+        if (have) {
+            const int pos = base + lane;
+            const bool valid = pos < n;
+            float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (valid) c = pts[pos];
+            sw.consider(c, pos, valid);
+            if (sw.npend < 64 * R) continue;
+        }
+        if (sw.npend > 0 || sw.empty) sw.flush();
+        if (!have) break;
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = lane + 64 * r;
+        if (i < k) {
+            const bool real = sw.best.p[r] != INT_MAX;
+            idx_out[q * k + i] = real ? sw.best.p[r] : n;
+            dist_out[q * k + i] = real ? sqrt(sw.best.d[r]) : (double)INFINITY;
+        }
+    }
+}
+
 // neighbour table -> public (rows,k) arrays for public rows [begin,end).  owned_pos == nullptr: the table came
 // from the exhaustive sweep (row = public index - q_begin, entries = public indices).
 __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ owned_pos, int q_begin,
@@ -1578,6 +1627,26 @@ int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, 
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, ctx->k, ctx->nbr_pitch, d_rows, d_idx,
                        d_dist, d_cnt);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t k, double eps, int32_t* d_idx, double* d_dist) {
+    if (!ctx->qpts4_valid) {
+        PCT_TRY(pct_reserve(ctx, &ctx->qpts4, (size_t)ctx->n * sizeof(float4)));
+        hipLaunchKernelGGL(k_plain_records, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream,
+                           ctx->xyz_view, ctx->n, (float4*)ctx->qpts4.p);
+        PCT_HIP(ctx, hipGetLastError());
+        ctx->qpts4_valid = true;
+    }
+    const double eps2 = eps > 0 ? eps * eps : (double)INFINITY;
+    const int blocks = (int)((m + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (k <= 64)
+        hipLaunchKernelGGL(k_query_points<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+                           (const float4*)ctx->qpts4.p, (int)ctx->n, d_q, m, k, eps2, d_idx, d_dist);
+    else
+        hipLaunchKernelGGL(k_query_points<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+                           (const float4*)ctx->qpts4.p, (int)ctx->n, d_q, m, k, eps2, d_idx, d_dist);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

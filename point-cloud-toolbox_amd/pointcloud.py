@@ -51,6 +51,36 @@ def _matrix_norms(points):
     return p.dtype.type(l1), p.dtype.type(l2), linf
 
 
+class _DeviceTree:
+    """``self.kdtree`` of the reference (SciPy's k-d tree of the float32 cloud, pct:74) as far as its callers use it
+    (pct:625, 759, 844): ``query(x, k)`` for arbitrary points, answered by the exhaustive device sweep
+    (``pct_query_points``).  Same return convention as SciPy: distances float64 ascending and indices, shape
+    ``x.shape[:-1] + (k,)`` (the ``k`` axis squeezed for ``k == 1``), missing entries ``inf`` / ``n``."""
+
+    def __init__(self, cloud):
+        self._cloud = cloud
+        self.n = cloud.num_points
+        self.m = 3
+
+    @property
+    def data(self):
+        return np.asarray(self._cloud.points, dtype=np.float32).astype(np.float64)
+
+    def query(self, x, k=1, eps=0, p=2, distance_upper_bound=np.inf, workers=1):
+        if eps != 0 or p != 2:
+            raise NotImplementedError("only exact Euclidean queries (eps=0, p=2) run on the device")
+        x = np.asarray(x, dtype=np.float64)
+        if x.shape[-1:] != (3,):
+            raise ValueError(f"x must consist of vectors of length 3 but has shape {x.shape}")
+        if not isinstance(k, (int, np.integer)) or k < 1:
+            raise ValueError("k must be an integer >= 1")
+        flat = x.reshape(-1, 3)
+        bound = float(distance_upper_bound)
+        idx, dist = self._cloud._ctx().query_points(flat, int(k), 0.0 if not np.isfinite(bound) else bound)
+        shape = x.shape[:-1] + ((int(k),) if k > 1 else ())
+        return dist.reshape(shape), idx.astype(np.intp).reshape(shape)
+
+
 class PointCloud:
 
     # pct:26 -- identical signature and defaults
@@ -143,6 +173,7 @@ class PointCloud:
             # bring them to the host before the device results are invalidated
             self._user_coefs = self.quadratic_coefficients
         h.knn(k_neighbors, eps or 0.0, algo)
+        self.kdtree = _DeviceTree(self)                     # pct:74-75: the tree object later methods query
         self._nbr_cache = None
         self._user_neighbors = None
         self._fit_on_device = False

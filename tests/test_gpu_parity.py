@@ -784,3 +784,42 @@ def test_handles_are_independent_across_threads(gpu):
             assert not isinstance(res, Exception), res
             for w, g in zip(want, res):
                 assert np.array_equal(w, g, equal_nan=True)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tree_query_for_arbitrary_points(gpu, dtype):
+    """``pc.kdtree.query(x, k)`` (pct:74; used at pct:625, 759, 844) against SciPy's tree of the float32 cloud:
+    off-cloud points, cloud points themselves (distance 0 first, nothing dropped), k = 1 squeeze, k > 64, an upper
+    bound, k > N padding.  Distances are float64 and must agree bit for bit; indices too (no ties in these clouds)."""
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(3)
+    pts = gpu["shapes"].torus_random(30_000, seed=21).astype(dtype)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(20)
+    ref = cKDTree(pts.astype(np.float32))
+    q = np.vstack([rng.normal(size=(200, 3)), pts[rng.choice(len(pts), 100, replace=False)].astype(np.float64),
+                   pts[:50].astype(np.float64) + 1e-4])
+    for k in (1, 5, 64, 65, 100, 128):
+        d, i = pc.kdtree.query(q, k)
+        rd, ri = ref.query(q, k)
+        assert d.dtype == np.float64 and d.shape == rd.shape and i.shape == ri.shape
+        assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    d, i = pc.kdtree.query(q[3], 7)                                  # a single point: (k,) arrays
+    rd, ri = ref.query(q[3], 7)
+    assert d.shape == (7,) and np.array_equal(d, rd) and np.array_equal(i, ri)
+    d, i = pc.kdtree.query(q[3])                                     # k = 1: scalars
+    rd, ri = ref.query(q[3])
+    assert np.ndim(d) == 0 and float(d) == float(rd) and int(i) == int(ri)
+    d, i = pc.kdtree.query(q, 30, distance_upper_bound=0.05)
+    rd, ri = ref.query(q, 30, distance_upper_bound=0.05)
+    assert np.array_equal(d, rd) and np.array_equal(i, ri) and np.isinf(d).any() and (i == len(pts)).any()
+    # the neighbour study's own query (pct:759-761): the point itself comes first
+    d, i = pc.kdtree.query(pc.points[17], 31)
+    assert i[0] == 17 and d[0] == 0.0 and np.array_equal(i[1:21], pc.neighbor_indices[17])
+    small = gpu["PointCloud"](points=pts[:40], normals=np.zeros((40, 0)))
+    small.plant_kdtree(5)
+    d, i = small.kdtree.query(q[:4], 50)                             # k > N: padded with N / inf
+    rd, ri = cKDTree(pts[:40].astype(np.float32)).query(q[:4], 50)
+    assert np.array_equal(d, rd) and np.array_equal(i, ri)
+    with pytest.raises(ValueError):
+        pc.kdtree.query(np.array([0.0, np.nan, 0.0]), 3)
