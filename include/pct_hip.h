@@ -120,6 +120,14 @@ int pct_fit(pct_ctx* ctx);
  * query[rows] (NULL = 0..rows-1), optional per-row valid count. */
 int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count,
                     const int64_t* query, int64_t rows, int32_t k);
+/* Diagnostics variant of pct_fit_indices: the same neighbourhoods through the same kernel, but the
+ * solution of the normal equations is returned unrounded (float64, where pct:359 casts to float32) and K, H are the
+ * formulas of pct:403-419 evaluated in float64 from it.  The design matrix stays float32 (pct:350, 358): this shows
+ * what the float32 rounding of the last two stages costs, not a different algorithm.  coefs (rows,6), K, H (rows)
+ * float64 host arrays.  Leaves the resident neighbour table and float32 results untouched. */
+int pct_fit_indices_f64(pct_ctx* ctx, const int32_t* idx, const int32_t* count,
+                        const int64_t* query, int64_t rows, int32_t k,
+                        double* coefs, double* K, double* H);
 /* plant_kdtree + compute_pointwise_explicit_quadratic_curvature (pct:505-509)
  * without materialising the neighbour table on the host. */
 int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pct_get_fit": (C.c_int, [_p, C.c_int64, C.c_int64, _f32p, _f32p, _f32p, _f32p]),
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
+    "pct_fit_indices_f64": (C.c_int, [_p, _i32p, _i32p, _i64p, C.c_int64, C.c_int32, _f64p, _f64p, _f64p]),
     "pct_query_points": (C.c_int, [_p, _f64p, C.c_int64, C.c_int32, C.c_double, _i32p, _f64p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
     "pct_voxel_downsample": (C.c_int, [_p, _f64p, C.c_int64, C.c_double, _i64p, _i64p]),
@@ -275,6 +276,19 @@ class Handle:
         self._check(self._lib.pct_fit_indices(self._h, _ptr(idx, _i32p), _ptr(cnt, _i32p), _ptr(qry, _i64p),
                                               idx.shape[0], idx.shape[1]))
         return idx.shape[0]
+
+    def fit_indices_f64(self, idx, count=None, query=None):
+        """Diagnostics: unrounded float64 coefficients (rows,6) and float64 K, H of the given neighbourhoods."""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        if idx.ndim != 2:
+            raise ValueError("neighbour indices must have shape (rows, k)")
+        cnt = None if count is None else np.ascontiguousarray(count, dtype=np.int32)
+        qry = None if query is None else np.ascontiguousarray(query, dtype=np.int64)
+        rows = idx.shape[0]
+        c, K, H = np.empty((rows, 6), np.float64), np.empty(rows, np.float64), np.empty(rows, np.float64)
+        self._check(self._lib.pct_fit_indices_f64(self._h, _ptr(idx, _i32p), _ptr(cnt, _i32p), _ptr(qry, _i64p), rows, idx.shape[1],
+                                                  _ptr(c, _f64p), _ptr(K, _f64p), _ptr(H, _f64p)))
+        return c, K, H
 
     def get_fit(self, begin, end, coefs=True, K=True, H=True, H2=True):
         rows = int(end) - int(begin)

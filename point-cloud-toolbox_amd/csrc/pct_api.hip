@@ -369,8 +369,9 @@ int pct_get_neighbor_rows(pct_ctx* ctx, const int64_t* rows, int64_t n_rows, int
     return PCT_OK;
 }
 
-int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k) {
-    PCT_TRY(begin_call(ctx));
+// validates host-supplied neighbour rows and stages them on the device (stage_a: ids with a 16-byte row pitch,
+// stage_c: counts, stage_d: query ids); the public-order records are packed if they are not resident
+static int stage_neighbour_rows(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k, int32_t* pitch_out, bool need_pts4) {
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
     if (!idx || rows <= 0 || k < 1 || k > 4096) return pct_fail(ctx, PCT_ERR_INVALID, "bad neighbour rows");
     // host-side validation: a bad index would fault the device
@@ -384,7 +385,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
             if (p[j] < 0 || p[j] >= ctx->n)
                 return pct_fail(ctx, PCT_ERR_INVALID, "row %lld: neighbour index %d out of range (IndexError in the reference)", (long long)r, p[j]);
     }
-    if (!ctx->pts4_valid) {
+    if (need_pts4 && !ctx->pts4_valid) {
         float bbox[6];
         PCT_TRY(pct_pack_points(ctx, bbox));
     }
@@ -402,6 +403,14 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
         PCT_TRY(pct_reserve(ctx, &ctx->stage_d, (size_t)rows * sizeof(int64_t)));
         PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_d.p, query, (size_t)rows * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream));
     }
+    *pitch_out = pitch;
+    return PCT_OK;
+}
+
+int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k) {
+    PCT_TRY(begin_call(ctx));
+    int32_t pitch = 0;
+    PCT_TRY(stage_neighbour_rows(ctx, idx, count, query, rows, k, &pitch, true));
     PCT_TRY(pct_reserve(ctx, &ctx->coefs, (size_t)rows * 6 * sizeof(float)));
     PCT_TRY(pct_reserve(ctx, &ctx->K, (size_t)rows * sizeof(float)));
     PCT_TRY(pct_reserve(ctx, &ctx->H, (size_t)rows * sizeof(float)));
@@ -418,6 +427,25 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     ctx->fit_valid = true;
     ctx->knn_valid = false;   // results are row-aligned now, not cloud-aligned
     return PCT_OK;
+}
+
+int pct_fit_indices_f64(pct_ctx* ctx, const int32_t* idx, const int32_t* count, const int64_t* query, int64_t rows, int32_t k,
+                        double* coefs, double* K, double* H) {
+    PCT_TRY(begin_call(ctx));
+    if (!coefs || !K || !H) return pct_fail(ctx, PCT_ERR_INVALID, "output arrays missing");
+    int32_t pitch = 0;
+    PCT_TRY(stage_neighbour_rows(ctx, idx, count, query, rows, k, &pitch, false));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)rows * 8 * sizeof(double)));
+    double* d_c = (double*)ctx->stage_b.p;
+    double* d_K = d_c + rows * 6;
+    double* d_H = d_K + rows;
+    PCT_TRY(pct_launch_fit_rows_f64(ctx, (const int*)ctx->stage_a.p, count ? (const int*)ctx->stage_c.p : nullptr,
+                                    query ? (const int64_t*)ctx->stage_d.p : nullptr, rows, k, pitch, d_c, d_K, d_H));
+    PCT_HIP(ctx, hipMemcpyAsync(coefs, d_c, (size_t)rows * 6 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(K, d_K, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(H, d_H, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;       // the resident float32 results and the neighbour table are untouched
 }
 
 int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, double eps, int32_t* idx, double* dist) {

@@ -48,6 +48,9 @@ struct FitArgs {
     float* K;
     float* H;
     float* H2;
+    double* coefs64;         // diagnostics variant (OUT64): unrounded coefficients and float64 curvatures, row-aligned
+    double* K64;
+    double* H64;
 };
 
 // One Jacobi rotation annihilating a_pq of a symmetric 3x3 (r = third index).
@@ -160,7 +163,7 @@ __device__ __forceinline__ void plane_rotation(int m, double sx, double sy, doub
     rot[0] = r00; rot[1] = r01; rot[2] = r02; rot[3] = r10; rot[4] = r11; rot[5] = r12; rot[6] = r20; rot[7] = r21; rot[8] = r22;
 }
 
-template <bool F64>
+template <bool F64, bool OUT64 = false>
 __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     extern __shared__ int s_idx[];   // 64 rows x kp
     const int lane = threadIdx.x;
@@ -208,8 +211,13 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     const float nanf_ = __int_as_float(0x7fc00000);
 
     if (m < 6) {   // under-determined quadric (only reachable through the eps bound)
-        for (int j = 0; j < 6; ++j) a.coefs[out * 6 + j] = nanf_;
-        a.K[out] = nanf_; a.H[out] = nanf_; a.H2[out] = nanf_;
+        if constexpr (OUT64) {
+            for (int j = 0; j < 6; ++j) a.coefs64[out * 6 + j] = (double)nanf_;
+            a.K64[out] = (double)nanf_; a.H64[out] = (double)nanf_;
+        } else {
+            for (int j = 0; j < 6; ++j) a.coefs[out * 6 + j] = nanf_;
+            a.K[out] = nanf_; a.H[out] = nanf_; a.H2[out] = nanf_;
+        }
         return;
     }
 
@@ -327,6 +335,17 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         b[i] = s * dinv[i];
     }
 #undef GI
+    if constexpr (OUT64) {
+        // diagnostics: what the float32 rounding of the coefficients (pct:359) and the float32 curvature arithmetic
+        // (pct:403-422) cost -- the solution as solved, and the same formulas in float64
+        double* co64 = a.coefs64 + out * 6;
+        for (int j = 0; j < 6; ++j) co64[j] = b[j];
+        const double Fx = b[3], Fy = b[4], Fxx = 2.0 * b[0], Fyy = 2.0 * b[1], Fxy = b[2];
+        const double wgt = (1.0 + Fx * Fx) + Fy * Fy;
+        a.K64[out] = (Fxx * Fyy - Fxy * Fxy) / (wgt * wgt);
+        a.H64[out] = (((1.0 + Fx * Fx) * Fyy - ((2.0 * Fx) * Fy) * Fxy) + (1.0 + Fy * Fy) * Fxx) / (2.0 * (wgt * sqrt(wgt)));
+        return;
+    }
     const float A = (float)b[0], B = (float)b[1], C = (float)b[2];
     const float D = (float)b[3], E = (float)b[4], F = (float)b[5];
     float* co = a.coefs + out * 6;
@@ -505,10 +524,15 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     const size_t lds = (size_t)kFitBlock * a.kp * sizeof(int);
     const int blocks = (int)((a.rows + kFitBlock - 1) / kFitBlock);
     if (blocks <= 0) return PCT_OK;
-    if (f64)
-        hipLaunchKernelGGL(k_fit<true>, dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+    if (a.coefs64) {
+        if (f64)
+            hipLaunchKernelGGL((k_fit<true, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+        else
+            hipLaunchKernelGGL((k_fit<false, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+    } else if (f64)
+        hipLaunchKernelGGL((k_fit<true, false>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_fit<false>, dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_fit<false, false>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -588,6 +612,28 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
         PCT_HIP(ctx, hipGetLastError());
     }
     return PCT_OK;
+}
+
+// the diagnostics variant of pct_launch_fit_rows: float64 coefficients and curvatures, public-space ids
+int pct_launch_fit_rows_f64(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query, int64_t rows,
+                            int32_t k, int32_t pitch, double* d_coefs, double* d_K, double* d_H) {
+    PCT_TRY(pct_ensure_plain_records(ctx));
+    FitArgs a = {};
+    a.pts = (const float4*)ctx->qpts4.p;
+    a.ptsd = ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr;
+    a.table = d_idx;
+    a.cnt = d_cnt;
+    a.row_query = d_query;
+    a.rows = rows;
+    a.k = k;
+    a.pitch = pitch;
+    a.out_by_row = 1;
+    a.q_begin = 0;
+    a.q_end = (int)ctx->n;
+    a.coefs64 = d_coefs;
+    a.K64 = d_K;
+    a.H64 = d_H;
+    return launch(ctx, a, ctx->has_f64);
 }
 
 int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_row, int64_t n_samples, int n_lo, int n_hi, int* d_table,

@@ -193,6 +193,9 @@ int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samp
 int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
+int pct_ensure_plain_records(pct_ctx* ctx);
+int pct_launch_fit_rows_f64(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query, int64_t rows,
+                            int32_t k, int32_t pitch, double* d_coefs, double* d_K, double* d_H);
 int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t k, double eps, int32_t* d_idx, double* d_dist);
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n);
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt);

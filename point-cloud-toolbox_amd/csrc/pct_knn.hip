@@ -1631,7 +1631,9 @@ int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, 
     return PCT_OK;
 }
 
-int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t k, double eps, int32_t* d_idx, double* d_dist) {
+// {x, y, z, index} records of every point in public order, kept apart from the sweep's own arrays (a side query or
+// a diagnostics fit must not disturb a resident table)
+int pct_ensure_plain_records(pct_ctx* ctx) {
     if (!ctx->qpts4_valid) {
         PCT_TRY(pct_reserve(ctx, &ctx->qpts4, (size_t)ctx->n * sizeof(float4)));
         hipLaunchKernelGGL(k_plain_records, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -1639,6 +1641,11 @@ int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t 
         PCT_HIP(ctx, hipGetLastError());
         ctx->qpts4_valid = true;
     }
+    return PCT_OK;
+}
+
+int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t k, double eps, int32_t* d_idx, double* d_dist) {
+    PCT_TRY(pct_ensure_plain_records(ctx));
     const double eps2 = eps > 0 ? eps * eps : (double)INFINITY;
     const int blocks = (int)((m + kWavesPerBlock - 1) / kWavesPerBlock);
     if (k <= 64)

@@ -823,3 +823,37 @@ def test_tree_query_for_arbitrary_points(gpu, dtype):
     assert np.array_equal(d, rd) and np.array_equal(i, ri)
     with pytest.raises(ValueError):
         pc.kdtree.query(np.array([0.0, np.nan, 0.0]), 3)
+
+
+def test_float64_diagnostics_fit(gpu):
+    """pct_fit_indices_f64: the unrounded solution rounds to the float32 coefficients bit for bit,
+    agrees with a float64 least-squares solve of the same float32 design rows, leaves the resident results alone,
+    and its float64 curvatures sit closer to the closed form of the surface than one float32 ulp of the formulas."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    pts, Kt, Ht = shapes.torus_random(40_000, seed=31, with_truth=True)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.curvature(50, 0.0, capi.KNN_GRID)
+    rows = np.arange(0, 40_000, 97, dtype=np.int64)
+    idx, _, _ = h.get_neighbor_rows(rows)
+    c32, K32, H32, _ = h.get_fit(0, 40_000)
+    c64, K64, H64 = h.fit_indices_f64(idx, query=rows)
+    assert c64.dtype == np.float64 and c64.shape == (len(rows), 6)
+    assert np.array_equal(c64.astype(np.float32), c32[rows])                 # pct:359's cast, nothing else
+    assert np.allclose(K64, K32[rows], rtol=2e-5, atol=1e-5) and np.allclose(H64, H32[rows], rtol=2e-5, atol=1e-5)
+    again = h.get_fit(0, 40_000)                                             # resident table and results untouched
+    assert np.array_equal(again[0], c32) and np.array_equal(again[1], K32)
+    assert np.array_equal(h.get_neighbor_rows(rows)[0], idx)
+    for r, nb in zip(rows[:60], idx[:60]):                                   # float64 lstsq on the oracle's design rows
+        rot = oracle.plane_align(pts[nb] - pts[r]).astype(np.float32)
+        X = np.column_stack([rot[:, 0] ** 2, rot[:, 1] ** 2, rot[:, 0] * rot[:, 1], rot[:, 0], rot[:, 1],
+                             np.ones(len(rot), np.float32)]).astype(np.float64)
+        sol = np.linalg.lstsq(X, rot[:, 2].astype(np.float64), rcond=None)[0]
+        got = c64[np.searchsorted(rows, r)]
+        assert np.allclose(got, sol, rtol=1e-7, atol=1e-9 * np.abs(sol).max())
+    with pytest.raises(ValueError):
+        h.fit_indices_f64(idx[:, :3] * 0 + 40_000)                           # out-of-range index
+    # eps rows with fewer than 6 neighbours: NaN, as the float32 path
+    c, K, H = h.fit_indices_f64(idx[:2], count=np.array([3, 50], np.int32), query=rows[:2])
+    assert np.isnan(c[0]).all() and np.isnan(K[0]) and np.isfinite(c[1]).all()
+    h.close()
