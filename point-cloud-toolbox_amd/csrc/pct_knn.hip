@@ -625,7 +625,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
-template <int R, bool EPS, bool PRE, bool PAIR = false>
+template <int R, bool EPS, bool PRE, bool PAIR = false, bool Q64 = false>
 __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
@@ -688,6 +688,12 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     if (lane < nq) {
         my_q = a.pts[qs + lane];
         if (a.ptsd) my_qd = a.ptsd[qs + lane];
+    }
+    float my_eq = 0.f;       // Q64: distance between the float64 query and its float32 rounding, rounded up
+    if constexpr (Q64) {
+        const double ex = my_qd.x - (double)my_q.x, ey = my_qd.y - (double)my_q.y, ez = my_qd.z - (double)my_q.z;
+        my_eq = (float)sqrt((ex * ex + ey * ey) + ez * ez) * (1.0f + 0x1p-22f);
+        if (!(my_eq >= 0.f)) my_eq = INFINITY;        // NaN cannot happen with finite inputs; be safe
     }
     // exclusive prefix of the run lengths over lanes 0..8 = first flat slot of every run; m = staged candidates
     int my_pre = 0, m = 0;
@@ -811,20 +817,53 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
     // eps^2 rounded up generously in float32: everything inside the eps ball passes the pre-selection, the exact
     // test follows on the survivors
     const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
+    const double eps1 = EPS ? sqrt(eps2) * (1.0 + 0x1p-50) : 0.0;       // eps itself, rounded up
 
     if constexpr (PRE && PAIR) {
         unsigned short* pend_b = s_pend2[w];
         const auto push_redo = [&](int row, int why) { note_redo(row, why); };
+        // smallest exact key a candidate cut by the float32 threshold T can have: its float32 d'^2 >= T means the
+        // exact d'^2 >= T (1 - 2^-20) (arithmetic error of the packed evaluation); for a float64 query the exact
+        // distance to the true query is at least d' - eq
+        const auto cut_key = [&](float T, double eq) {
+            double lo2 = (double)T * (1.0 - 0x1p-20);
+            if constexpr (Q64) {
+                // (sqrt(L) - eq)^2 >= L - 2 eq sqrt(L); an upper bound of the root is enough: float32 root, rounded up
+                const double root_up = (double)__builtin_sqrtf(T) * (1.0 + 0x1p-21);
+                lo2 = fmax(lo2 - 2.0 * eq * root_up, 0.0);
+            }
+            return (unsigned)fmin(lo2 * scale, 4294967294.0);
+        };
         for (int qi = 0; qi < nq; qi += 2) {
             const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
             const int qj = live_b ? qi + 1 : qi;
             const int row_a = row0 + qi, row_b = row0 + qj;
-            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
-            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
-            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
-            const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
-            const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
-            const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
+            float ax, ay, az, bx, by, bz;
+            if constexpr (!Q64) {
+                ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+                ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+                az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+                bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
+                by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
+                bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
+            }
+            // Float64 cloud (Q64): the candidates are the float32-rounded points (the reference's tree data, pct:74) and
+            // my_q is the query ROUNDED to float32, so the pre-selection measures distances to a point that lies
+            // eq = |q64 - q32| away from the true query: every bound taken from it moves by eq (triangle inequality).
+            double qax, qay, qaz, qbx, qby, qbz, eq_a = 0.0, eq_b = 0.0;
+            if constexpr (Q64) {
+                const auto rl = [&](double v, int l) {
+                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+                };
+                qax = rl(my_qd.x, qi); qay = rl(my_qd.y, qi); qaz = rl(my_qd.z, qi);
+                qbx = rl(my_qd.x, qj); qby = rl(my_qd.y, qj); qbz = rl(my_qd.z, qj);
+                ax = (float)qax; ay = (float)qay; az = (float)qaz;         // == the float32 record of the point (k_pack_f64)
+                bx = (float)qbx; by = (float)qby; bz = (float)qbz;
+                eq_a = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qi));
+                eq_b = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qj));
+            } else {
+                qax = (double)ax; qay = (double)ay; qaz = (double)az; qbx = (double)bx; qby = (double)by; qbz = (double)bz;
+            }
             // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
             float ap_a[NB], ap_b[NB];
 #pragma unroll
@@ -855,6 +894,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
             // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball ----------------------
             float T_a = EPS ? eps2a : INFINITY, T_b = T_a;
+            if constexpr (EPS && Q64) {          // exact d < eps  =>  d' < eps + eq
+                const double ea = eps1 + eq_a, eb = eps1 + eq_b;
+                T_a = (float)fmin(ea * ea * (1.0 + 0x1p-18), 3.0e38);
+                T_b = (float)fmin(eb * eb * (1.0 + 0x1p-18), 3.0e38);
+            }
             int tot_a = m, tot_b = m;
             if constexpr (EPS) {
                 tot_a = tot_b = 0;
@@ -907,11 +951,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                 }
                 if (need_a) {
                     ok_a = found_a && T_a >= 1e-30f;
-                    if (ok_a) { t_prev_f = T_a; bkey_a = (unsigned)fmin((double)T_a * (1.0 - 0x1p-20) * scale, 4294967294.0); }
+                    if (ok_a) { t_prev_f = T_a; bkey_a = cut_key(T_a, eq_a); }
                 }
                 if (need_b) {
                     ok_b = ok_b && found_b && T_b >= 1e-30f;
-                    if (ok_b) { t_prev_f = T_b; bkey_b = (unsigned)fmin((double)T_b * (1.0 - 0x1p-20) * scale, 4294967294.0); }
+                    if (ok_b) { t_prev_f = T_b; bkey_b = cut_key(T_b, eq_b); }
                 }
                 if (!ok_a) { push_redo(row_a, 3); T_a = 0.f; cnt_a = 0; }        // nothing passes, nothing is stored
                 if (!ok_b) { if (live_b) push_redo(row_b, 3); T_b = 0.f; cnt_b = 0; }
@@ -945,7 +989,6 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     }
                 }
                 wave_lds_sync();
-                const double qax = (double)ax, qay = (double)ay, qaz = (double)az, qbx = (double)bx, qby = (double)by, qbz = (double)bz;
                 // Survivor i's exact distance and sorted position are worked out here, by the lane that holds its
                 // coordinates anyway, and parked in that lane (out_d / out_p); after the sort the lane that ends up
                 // with list entry i fetches them with one cross-lane read each instead of recomputing them.
@@ -1551,12 +1594,27 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         // so such clouds take the variant that keys every candidate in float64.
         const double c2 = ctx->grid.cell * ctx->grid.cell;
         const bool f32_ok = c2 > 1e-30 && c2 < 1e30 && (!(eps > 0) || eps * eps > 1e-36);
+        // Float64 clouds take the paired pre-selecting variant too (Q64: bounds widened by the rounding distance of the
+        // query) unless that distance is not small against a cell edge -- coordinates so large that float32 resolves
+        // them barely finer than the cells: there every query would be sent to the exact sweep.
+        const pct_grid& gg = ctx->grid;
+        const double far = fmax(fmax(fabs(gg.ox), fabs(gg.ox + gg.nx * gg.cell)),
+                                fmax(fmax(fabs(gg.oy), fabs(gg.oy + gg.ny * gg.cell)), fmax(fabs(gg.oz), fabs(gg.oz + gg.nz * gg.cell))));
+        const bool q64_ok = ctx->has_f64 && f32_ok && far * 0x1p-23 < gg.cell * 0x1p-7 && !ctx->level_mode;
         const bool e = eps > 0, pre = !ctx->has_f64 && f32_ok, r1 = k + 1 <= pct_fast_r1_max();
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         static const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;          // tuning aid
 #define PCT_FAST_PAIR(R_, E_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+#define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
+    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (q64_ok && !no_pair) {
+            if (r1 && !e) PCT_FAST_PAIR64(1, false, grid1, block1);
+            else if (r1) PCT_FAST_PAIR64(1, true, grid1, block1);
+            else if (!e) PCT_FAST_PAIR64(2, false, grid2, block2);
+            else PCT_FAST_PAIR64(2, true, grid2, block2);
+        } else
         if (r1 && !e && pre && !no_pair) PCT_FAST_PAIR(1, false, grid1, block1);
         else if (r1 && e && pre && !no_pair) PCT_FAST_PAIR(1, true, grid1, block1);
         else if (!r1 && !e && pre && !no_pair) PCT_FAST_PAIR(2, false, grid2, block2);
@@ -1571,6 +1629,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         else PCT_FAST(2, true, false, grid2, block2);
 #undef PCT_FAST
 #undef PCT_FAST_PAIR
+#undef PCT_FAST_PAIR64
         PCT_HIP(ctx, hipGetLastError());
     }
     PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));      // end of the dominant kernel

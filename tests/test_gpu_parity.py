@@ -857,3 +857,33 @@ def test_float64_diagnostics_fit(gpu):
     c, K, H = h.fit_indices_f64(idx[:2], count=np.array([3, 50], np.int32), query=rows[:2])
     assert np.isnan(c[0]).all() and np.isnan(K[0]) and np.isfinite(c[1]).all()
     h.close()
+
+
+@pytest.mark.parametrize("offset,scale", [(3.0, 0.01), (40.0, 0.2), (0.0, 1.0)])
+def test_float64_cloud_whose_float32_rounding_is_coarse(gpu, offset, scale):
+    """Float64 queries against the float32-rounded tree data (pct:74, 83) where the rounding distance of a query is a
+    visible fraction of its neighbour distances: the pre-selecting sweep's bounds must absorb it (Q64 variant), with
+    and without an eps ball, k below and above 64 -- bit-identical to the exhaustive sweep."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(60_000, seed=77, dtype=np.float64) * scale + offset
+    h = capi.Handle(0)
+    h.set_points(pts)
+    spacing = scale * 0.02
+    for k, eps in ((50, 0.0), (80, 0.0), (30, 2.5 * spacing), (100, 6.0 * spacing)):
+        h.curvature(k, eps, capi.KNN_BRUTE)
+        want = h.get_neighbors(0, len(pts), want_count=True) + h.get_fit(0, len(pts))[:3]
+        h.curvature(k, eps, capi.KNN_GRID)
+        got = h.get_neighbors(0, len(pts), want_count=True) + h.get_fit(0, len(pts))[:3]
+        for w, g in zip(want, got):
+            assert np.array_equal(w, g, equal_nan=True)
+        if eps:
+            assert 0 < want[2].min() < k or want[2].max() == k
+    idx, d = oracle.knn(pts, 20)
+    h.knn(20, algo=capi.KNN_GRID)
+    gi, gd, _ = h.get_neighbors(0, len(pts))
+    assert np.array_equal(gd, d)
+    for r in np.where((gi != idx).any(1))[0]:          # points that coincide after the float32 rounding: exact ties,
+        c = np.where(gi[r] != idx[r])[0]                # ordered by index here, arbitrarily by SciPy (DESIGN section 7)
+        assert sorted(gi[r][c]) == sorted(idx[r][c]) or (c[-1] == 19 and (d[r][c] == d[r][c[0]]).all())
+    assert (gi != idx).any(1).sum() < 20
+    h.close()
