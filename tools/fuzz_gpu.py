@@ -8,6 +8,9 @@ import __graft_entry__ as ge
 ge.build()
 from point_cloud_toolbox_amd import _capi, shapes
 
+F64_SHARE = float(os.environ.get("FUZZ_F64_SHARE", "0.15"))       # share of float64 clouds
+
+
 def make_case(seed0, it):
     """The random case (seed0, it): returns (rng, pts, n, k, kind, eps)."""
     rng = np.random.default_rng([seed0, it])
@@ -43,7 +46,7 @@ def make_case(seed0, it):
         pts = rng.uniform(0, 1, size=(n, 3)) * [1, 1e-3, 1e-6]
     else:                                                                                   # extreme magnitudes (float32 squares overflow / underflow)
         pts = shapes.torus_random(n, seed=int(rng.integers(1 << 30))).astype(np.float64) * 10.0 ** rng.choice([-30, -22, -15, 12, 18, 25, 30])
-    pts = np.ascontiguousarray(pts, dtype=np.float64 if rng.random() < 0.15 else np.float32)
+    pts = np.ascontiguousarray(pts, dtype=np.float64 if rng.random() < F64_SHARE else np.float32)
     eps = 0.0
     if rng.random() < 0.3:
         ext = float(np.ptp(pts, axis=0).max())
