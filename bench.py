@@ -29,7 +29,7 @@ HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def measured_traffic(n_points, k):
     """HBM bytes per sweep launch from the committed PMC passes (FETCH_SIZE x2 + WRITE_SIZE, see the file)."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_n_knn_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r01_o_knn_traffic.json")) as f:
             d = json.load(f)
         if n_points == 1_000_000 and k == 50:
             return d["hbm_bytes_per_launch"]
