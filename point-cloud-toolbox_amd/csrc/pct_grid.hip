@@ -740,6 +740,14 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                 !getenv("PCT_NO_SPEC");
     if (try_cull) {
         PCT_TRY(pack_near_owned(ctx, target, bbox, &red, &kept_box));
+        if (ctx->n_grid < (int64_t)k + 1) {
+            // The kept part cannot even fill a row (a few owned rows and a culling box -- possibly a stale one of the
+            // previous cloud -- that holds nobody else): the table would carry "missing" entries that the fused fit,
+            // launched before the limits are checked, must never see without a count array.  Take every point.
+            ctx->no_cull = true;
+            ctx->cull_box_valid = false;
+            return pct_build_grid(ctx, k, eps);
+        }
         PCT_TRY(trim_box(ctx, red, bbox));
     } else if (spec) {
         PCT_TRY(pack_all(ctx, bbox, &red, true));

@@ -681,6 +681,15 @@ def test_random_cross_check_large_and_tiny(gpu):
     assert done >= 100
 
 
+def test_random_stream_of_clouds_through_one_handle(gpu):
+    """Fixed-seed slice of tools/fuzz_stream.py: the warm-start state a handle keeps between calls (cell-edge hint,
+    speculative box, reused culling box) never changes a result -- same-size clouds that move, shrink or change
+    density, owned ranges that change or stay, against the exhaustive sweep of a fresh handle."""
+    done, bad = _tool("fuzz_stream").run(seed0=1, budget=40.0, cases=400, verbose=False)
+    assert bad is None, bad
+    assert done >= 100
+
+
 def test_edge_calls(gpu):
     """Degenerate requests end in the reference's exceptions or in well-defined results, never in a crash."""
     capi = gpu["capi"]
@@ -886,4 +895,28 @@ def test_float64_cloud_whose_float32_rounding_is_coarse(gpu, offset, scale):
         c = np.where(gi[r] != idx[r])[0]                # ordered by index here, arbitrarily by SciPy
         assert sorted(gi[r][c]) == sorted(idx[r][c]) or (c[-1] == 19 and (d[r][c] == d[r][c[0]]).all())
     assert (gi != idx).any(1).sum() < 20
+    h.close()
+
+
+def test_tiny_shard_after_the_cloud_moved(gpu):
+    """A handle that owns a handful of rows reuses the neighbourhood box of its previous, similar call; when the next
+    cloud of the same size lies elsewhere that box holds none of it, the kept part (the owned rows alone) cannot fill
+    a row of k neighbours, and the sweep must take every point instead of handing the fused fit a table with missing
+    entries (tools/fuzz_stream.py found the out-of-bounds gather this used to end in)."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    n, lo, hi, k = 17_294, 7639, 7653, 20
+    h = capi.Handle(0)
+    a = shapes.egg_carton_random(n, seed=1) * np.float32(0.017)
+    b = shapes.torus_random(n, seed=2) + np.array([59.8, 43.0, 25.4], np.float32)
+    for pts in (a, b, a, b):
+        h.set_points(pts)
+        h.set_query_range(lo, hi)
+        h.curvature(k, 0.0, capi.KNN_GRID)
+        got = h.get_neighbors(lo, hi) + h.get_fit(lo, hi)[:3]
+        f = capi.Handle(0)
+        f.set_points(pts); f.set_query_range(lo, hi); f.curvature(k, 0.0, capi.KNN_BRUTE)
+        want = f.get_neighbors(lo, hi) + f.get_fit(lo, hi)[:3]
+        f.close()
+        for w, g in zip(want[:2] + want[3:], got[:2] + got[3:]):
+            assert np.array_equal(w, g, equal_nan=True)
     h.close()
