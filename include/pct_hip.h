@@ -172,7 +172,9 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
 /* ---- scan preparation (next row N4) ---------------------------------------- */
 /* Voxel-grid down-sampling of convert_asc_to_ply.py:20-51: voxel = floor(coordinate / voxel_size) in float64, the
  * first point of every voxel is kept.  indices (caller-allocated, n entries) receives the kept input indices in
- * increasing order (= the reference's order of first occurrence), *count their number. */
+ * increasing order (= the reference's order of first occurrence), *count their number.  Works on any handle, with or
+ * without a resident cloud; it borrows the cell list's scratch buffers, so a resident neighbour table is dropped
+ * (plant it again before pct_fit / pct_get_neighbors); fit results already computed stay readable. */
 int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count);
 /* PCA surface variation of utils.py:778-829 for the loaded cloud: k_total neighbours including the point itself,
  * out[i] = lambda_min / (lambda_0 + lambda_1 + lambda_2 + 1e-10), (owned rows) float32. */

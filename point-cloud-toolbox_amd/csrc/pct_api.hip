@@ -299,6 +299,7 @@ int pct_fit(pct_ctx* ctx) {
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
     ctx->fit_valid = true;
+    ctx->fit_cloud_aligned = true;
     return PCT_OK;
 }
 
@@ -320,6 +321,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
     ctx->fit_valid = true;
+    ctx->fit_cloud_aligned = true;
     return PCT_OK;
 }
 
@@ -425,7 +427,8 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     ctx->fit_rows = rows;
     ctx->fit_row_order = false;
     ctx->fit_valid = true;
-    ctx->knn_valid = false;   // results are row-aligned now, not cloud-aligned
+    ctx->fit_cloud_aligned = false;
+    ctx->knn_valid = false;   // the caller's rows are the neighbourhoods of record now, not the resident table
     return PCT_OK;
 }
 
@@ -471,7 +474,7 @@ int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, do
 int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end, float* coefs, float* K, float* H, float* H2) {
     PCT_TRY(begin_call(ctx));
     if (!ctx->fit_valid) return pct_fail(ctx, PCT_ERR_INVALID, "no fit results");
-    const int64_t base = ctx->knn_valid ? ctx->q_begin : 0;   // cloud-aligned vs row-aligned results
+    const int64_t base = ctx->fit_cloud_aligned ? ctx->q_begin : 0;   // cloud-aligned vs row-aligned results
     if (begin < base || end > base + ctx->fit_rows || begin > end)
         return pct_fail(ctx, PCT_ERR_INVALID, "rows [%lld,%lld) outside the fitted range", (long long)begin, (long long)end);
     const int64_t rows = end - begin, off = begin - base;

@@ -123,6 +123,8 @@ struct pct_ctx {
     int64_t fit_rows = 0;
     bool fit_valid = false;
     bool fit_row_order = false;    // results are in neighbour-table row order (grid sweep), not public order
+    bool fit_cloud_aligned = false;// results belong to cloud rows [q_begin, q_end) (pct_fit / pct_curvature) rather than to the
+                                   // rows of a pct_fit_indices call; kept apart from knn_valid, which helpers may clear
 
     // staging for downloads / host-index fits
     pct_buf stage_a, stage_b, stage_c, stage_d;

@@ -920,3 +920,33 @@ def test_tiny_shard_after_the_cloud_moved(gpu):
         for w, g in zip(want[:2] + want[3:], got[:2] + got[3:]):
             assert np.array_equal(w, g, equal_nan=True)
     h.close()
+
+
+def test_fit_results_survive_a_helper_call_on_a_sharded_handle(gpu):
+    """pct_voxel_downsample borrows the cell list's scratch and drops the neighbour table; the fit results of a
+    sharded handle must still be addressed by cloud row afterwards (they were mistaken for row-aligned results)."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(20_000, seed=9)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.set_query_range(5000, 9000)
+    h.curvature(30, 0.0, capi.KNN_GRID)
+    before = h.get_fit(6000, 7000)
+    kept = h.voxel_downsample(pts, 0.05)
+    assert 0 < len(kept) < len(pts)
+    after = h.get_fit(6000, 7000)
+    for b, a in zip(before, after):
+        assert np.array_equal(b, a)
+    with pytest.raises(AttributeError):
+        h.get_neighbors(6000, 7000)                      # the table is gone, as documented
+    with pytest.raises(ValueError):
+        h.get_fit(0, 100)                                # still outside the owned range
+    h.close()
+
+
+def test_random_call_sequences(gpu):
+    """Fixed-seed slice of tools/fuzz_api.py: random valid sequences of C-ABI calls on one handle, every result equal
+    to a fresh handle's exhaustive answer for that request alone."""
+    done, bad = _tool("fuzz_api").run(seed0=5, budget=40.0, cases=6000)
+    assert bad is None, bad
+    assert done >= 1000
