@@ -117,7 +117,8 @@ int pct_get_neighbor_rows(pct_ctx* ctx, const int64_t* rows, int64_t n_rows,
 /* From the device-resident neighbour table left by pct_knn. */
 int pct_fit(pct_ctx* ctx);
 /* From host-supplied neighbours: idx (rows,k) int32 for query points
- * query[rows] (NULL = 0..rows-1), optional per-row valid count. */
+ * query[rows] (NULL = 0..rows-1), optional per-row valid count.  The results replace those of an
+ * earlier fit; a resident neighbour table stays as it is (pct_get_neighbors / pct_fit keep working). */
 int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count,
                     const int64_t* query, int64_t rows, int32_t k);
 /* Diagnostics variant of pct_fit_indices: the same neighbourhoods through the same kernel, but the

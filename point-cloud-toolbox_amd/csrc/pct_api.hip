@@ -427,8 +427,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     ctx->fit_rows = rows;
     ctx->fit_row_order = false;
     ctx->fit_valid = true;
-    ctx->fit_cloud_aligned = false;
-    ctx->knn_valid = false;   // the caller's rows are the neighbourhoods of record now, not the resident table
+    ctx->fit_cloud_aligned = false;   // (a resident neighbour table is untouched and stays valid)
     return PCT_OK;
 }
 

@@ -151,10 +151,17 @@ class PointCloud:
         return self._handle
 
     def close(self):
+        """Release the device handle (an extension: the reference holds no device state).  Fitted coefficients that
+        still live on the device are brought to the host first (24 B/point), so ``quadratic_coefficients`` and a later
+        ``calculate_curvatures_...`` keep working; the neighbour table is dropped unless it has been read already."""
         if self._handle is not None:
+            if self._fit_on_device and self._user_coefs is None:
+                self._user_coefs = self.quadratic_coefficients
             self._handle.close()
             self._handle = None
             self._cloud_on_device = False
+            self._fit_on_device = False
+            self._device_curv = None
 
     # ------------------------------------------------------------------ A3
     def plant_kdtree(self, k_neighbors, eps=None, algorithm="auto"):
@@ -197,8 +204,7 @@ class PointCloud:
 
     @neighbor_indices.setter
     def neighbor_indices(self, value):
-        self._user_neighbors = np.asarray(value)
-        self._fit_on_device = False
+        self._user_neighbors = np.asarray(value)      # used by the next fit; what has been fitted already stays (pct:637)
 
     @property
     def dists(self):

@@ -383,9 +383,21 @@ def test_shard_whose_neighbours_lie_past_the_kept_part_is_redone(gpu):
     h.set_query_range(0, 20)
     h.knn(30, algo=capi.KNN_GRID)
     t = h.timings()
-    assert t["limit_retries"] == 1 and t["grid_points"] == len(pts)
+    assert t["grid_points"] == len(pts)                  # 20 kept points cannot fill a row of 30: every point is taken at once
     i, dd, _ = h.get_neighbors(0, 20)
     assert np.array_equal(i, idx[:20]) and np.array_equal(dd, d[:20])
+    # enough kept points to fill the rows, but the 30th neighbour of a row lies farther than the kept box reaches:
+    # 40 owned points along a line, everything else beside it
+    line = np.stack([np.linspace(0, 1, 40), np.zeros(40), np.zeros(40)], 1) + rng.normal(scale=1e-4, size=(40, 3))
+    pts = np.vstack([line, rng.uniform(-0.2, 1.2, size=(30_000, 3)) * [1, 1, 0] + [0, 0, 0.35]]).astype(np.float32)
+    idx, d = oracle.knn(pts, 30)
+    h.set_points(pts)
+    h.set_query_range(0, 40)
+    h.knn(30, algo=capi.KNN_GRID)
+    t = h.timings()
+    assert t["limit_retries"] == 1 and t["grid_points"] == len(pts)
+    i, dd, _ = h.get_neighbors(0, 40)
+    assert np.array_equal(i, idx[:40]) and np.array_equal(dd, d[:40])
     h.close()
 
 
@@ -950,3 +962,42 @@ def test_random_call_sequences(gpu):
     done, bad = _tool("fuzz_api").run(seed0=5, budget=40.0, cases=6000)
     assert bad is None, bad
     assert done >= 1000
+
+
+def test_attributes_outlive_the_calls_that_follow(gpu):
+    """Host-state regressions found by tools/fuzz_pointcloud.py: what the reference keeps as plain attributes stays
+    readable here whatever is called next -- coefficients across `neighbor_indices = ...` + re-planting (Q16),
+    coefficients and curvatures across close(), `dists` after a fit from a caller-supplied table."""
+    pts = gpu["shapes"].torus_random(3000, seed=4)
+    ref15, ref30 = oracle.pipeline_batched(pts, 15), oracle.pipeline_batched(pts, 30)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(15)
+    pc.fit_explicit_quadratic_surfaces_to_neighborhoods()
+    pc.neighbor_indices = ref15["idx"].copy()
+    pc.plant_kdtree(30)                                               # utils.py:495-501: re-plant without re-fitting
+    assert (np.asarray(pc.quadratic_coefficients) == ref15["coefs"]).all(1).mean() > 0.99
+    K, H = pc.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
+    assert_curvature(K, H, ref15["K"], ref15["H"])
+    assert np.array_equal(pc.neighbor_indices, ref30["idx"])
+
+    pc.compute_pointwise_explicit_quadratic_curvature()               # k = 30 results on the device ...
+    pc.close()                                                        # ... and the handle goes away
+    assert (np.asarray(pc.quadratic_coefficients) == ref30["coefs"]).all(1).mean() > 0.99
+    assert_curvature(pc.K_quadratic, pc.H_quadratic, ref30["K"], ref30["H"])
+    K, H = pc.calculate_curvatures_of_explicit_quadratic_surfaces_for_all_points()
+    assert_curvature(K, H, ref30["K"], ref30["H"])
+
+    pc.plant_kdtree(15)
+    pc.neighbor_indices = ref15["idx"].copy()
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()        # fit from the caller's table
+    assert_curvature(K, H, ref15["K"], ref15["H"])
+    assert np.array_equal(pc.dists, ref15["dists"])                   # the planted distances are still there
+    pc.close()
+
+
+def test_random_pointcloud_call_sequences(gpu):
+    """Fixed-seed slice of tools/fuzz_pointcloud.py: the class's methods and attributes in random valid order against
+    the oracle."""
+    done, bad = _tool("fuzz_pointcloud").run(seed0=2, budget=40.0, cases=1500)
+    assert bad is None, bad
+    assert done >= 300

@@ -106,7 +106,7 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
             idx, _, cnt = h.get_neighbor_rows(rows)
             idx = np.where(idx >= n, 0, idx)                   # padding entries lie beyond the count
             if op == "rows_fit":
-                h.fit_indices(idx, count=cnt, query=rows); knn = None; fit = ("rows", rows, k, eps)
+                h.fit_indices(idx, count=cnt, query=rows); fit = ("rows", rows, k, eps)
             else:
                 c64, K64, H64 = h.fit_indices_f64(idx, count=cnt, query=rows); want = ref.table(k, eps)
                 if not same(c64.astype(np.float32), want[3][rows]): return fail("fit_indices_f64 does not round to the float32 coefficients")
