@@ -26,6 +26,7 @@ def run(seed0=0, budget=None, cases=None, verbose=True):
     t_end = time.time() + (budget if budget is not None else 1e9)
     rng = np.random.default_rng([seed0, 4242])
     h = _capi.Handle(0)
+    dev = None
     n = int(rng.integers(2000, 40_000)); it = 0
     lo, hi = 0, n
     while time.time() < t_end and (cases is None or it < cases):
@@ -42,7 +43,13 @@ def run(seed0=0, budget=None, cases=None, verbose=True):
         k = int(rng.choice([5, 20, 50, 64, 90])); k = min(k, n - 1)
         eps = float(np.ptp(pts, axis=0).max()) * 10.0 ** rng.uniform(-2.3, -1.0) if rng.random() < 0.25 else 0.0
         if verbose: print(f"case {it}: n={n} [{lo},{hi}) k={k} eps={eps:.3g} {pts.dtype} ...", flush=True)
-        h.set_points(pts)
+        if pts.dtype == np.float32 and rng.random() < 0.5:
+            # zero-copy hand-over, the multi-GPU step's way: ONE device buffer, rewritten in place for every cloud
+            if dev is None: dev = h.device_alloc(40_000 * 12)
+            h.device_upload(dev, pts)
+            h.use_points_device(dev, n)
+        else:
+            h.set_points(pts)
         h.set_query_range(lo, hi)
         h.curvature(k, eps, _capi.KNN_GRID)
         if verbose: print("   grid sweep done", flush=True)
@@ -53,9 +60,11 @@ def run(seed0=0, budget=None, cases=None, verbose=True):
         ok = all(np.array_equal(w, g, equal_nan=True) for w, g in zip(want, got))
         if verbose: print(f"   ok={ok}", flush=True)
         if not ok:
+            if dev is not None: h.device_free(dev)
             h.close()
             return it, f"seed={seed0} case {it}: n={n} [{lo},{hi}) k={k} eps={eps} dtype={pts.dtype}"
         it += 1
+    if dev is not None: h.device_free(dev)
     h.close()
     return it, None
 
