@@ -57,7 +57,7 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
         h.close()
         return it, f"seed={seed0} step {it}: {msg}; last ops: {log[-8:]}"
     while time.time() < t_end and (cases is None or it < cases):
-        ops = ["cloud"] if pts is None else ["cloud", "range", "knn", "knn", "curv", "curv", "stats", "factor", "query", "voxel"]
+        ops = ["cloud"] if pts is None else ["cloud", "range", "knn", "knn", "curv", "curv", "stats", "factor", "query", "voxel", "survar"]
         if knn: ops += ["fit", "get_nbr", "get_rows", "rows_fit", "rows_fit64", "study"]
         if fit: ops += ["get_fit", "get_fit"]
         w = np.array([0.25 if o in ("cloud", "range") else 0.5 if o in ("stats", "factor", "voxel") else 1.0 for o in ops]) if pts is not None else None
@@ -123,6 +123,13 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
             got = h.query_points(q, kq)
             f = _capi.Handle(0); f.set_points(pts); want = f.query_points(q, kq); f.close()
             if not (same(got[0], want[0]) and same(got[1], want[1])): return fail("query_points")
+        elif op == "survar":                                        # PCA surface variation: plants its own table, drops the fit
+            kt = min(int(rng.choice([8, 20, 40])), n - 1)
+            if lo == 0 and hi == n:
+                got = h.surface_variation(kt)
+                f = _capi.Handle(0); f.set_points(pts); want = f.surface_variation(kt); f.close()
+                if not same(got, want): return fail("surface_variation")
+                knn = (kt - 1, 0.0, lo, hi); fit = None
         elif op == "voxel":
             v = float(np.ptp(pts, axis=0).max()) * 10.0 ** rng.uniform(-2, -0.5)
             got = h.voxel_downsample(pts, v)
