@@ -22,16 +22,19 @@ def cloud(rng, n):
     return p
 
 
+N_MAX = int(os.environ.get("FUZZ_N_MAX", "40000"))      # largest cloud of the stream
+
+
 def run(seed0=0, budget=None, cases=None, verbose=True):
     t_end = time.time() + (budget if budget is not None else 1e9)
     rng = np.random.default_rng([seed0, 4242])
     h = _capi.Handle(0)
     dev = None
-    n = int(rng.integers(2000, 40_000)); it = 0
+    n = int(rng.integers(2000, N_MAX)); it = 0
     lo, hi = 0, n
     while time.time() < t_end and (cases is None or it < cases):
         r = rng.random()
-        if r < 0.25: n = int(rng.integers(2000, 40_000)); lo, hi = 0, n           # a different size
+        if r < 0.25: n = int(rng.integers(2000, N_MAX)); lo, hi = 0, n           # a different size
         pts = cloud(rng, n)
         r = rng.random()
         if r < 0.3: pts = pts * 10.0 ** rng.uniform(-2, 2)                           # same size, another scale
@@ -45,7 +48,7 @@ def run(seed0=0, budget=None, cases=None, verbose=True):
         if verbose: print(f"case {it}: n={n} [{lo},{hi}) k={k} eps={eps:.3g} {pts.dtype} ...", flush=True)
         if pts.dtype == np.float32 and rng.random() < 0.5:
             # zero-copy hand-over, the multi-GPU step's way: ONE device buffer, rewritten in place for every cloud
-            if dev is None: dev = h.device_alloc(40_000 * 12)
+            if dev is None: dev = h.device_alloc(N_MAX * 12)
             h.device_upload(dev, pts)
             h.use_points_device(dev, n)
         else:
