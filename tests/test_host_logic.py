@@ -71,3 +71,28 @@ def test_shapes_are_reproducible_and_shardable(built):
     assert np.allclose(np.linalg.norm(s, axis=1), 1, atol=1e-6)
     t = sh.tile_cloud(np.random.default_rng(0).random((10, 3)) * 0.1, 5)
     assert t.shape == (50, 3) and t.dtype == np.float32
+
+
+def test_tree_wrapper_checks_its_arguments_before_touching_the_device(built):
+    """`PointCloud.kdtree` mirrors SciPy's `query` signature; what the device sweep cannot answer is refused up
+    front (no silent host fallback), malformed input raises as SciPy does."""
+    from point_cloud_toolbox_amd.pointcloud import _DeviceTree
+
+    class Cloud:                          # stands in for a PointCloud: the checks run before any device call
+        num_points = 10
+        points = np.zeros((10, 3), np.float32)
+        def _ctx(self):
+            raise AssertionError("argument checks must come first")
+
+    t = _DeviceTree(Cloud())
+    assert t.n == 10 and t.m == 3 and t.data.dtype == np.float64 and t.data.shape == (10, 3)
+    with pytest.raises(NotImplementedError):
+        t.query(np.zeros(3), 2, eps=0.1)                  # approximate search
+    with pytest.raises(NotImplementedError):
+        t.query(np.zeros(3), 2, p=1)                      # another metric
+    with pytest.raises(ValueError):
+        t.query(np.zeros(4), 2)
+    with pytest.raises(ValueError):
+        t.query(np.zeros(3), 0)
+    with pytest.raises(ValueError):
+        t.query(np.zeros(3), 2.5)
