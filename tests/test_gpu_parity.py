@@ -1001,3 +1001,34 @@ def test_random_pointcloud_call_sequences(gpu):
     done, bad = _tool("fuzz_pointcloud").run(seed0=2, budget=40.0, cases=1500)
     assert bad is None, bad
     assert done >= 300
+
+
+def test_handles_give_their_memory_back(gpu):
+    """Create / use / destroy: the device memory of a handle (cloud, cell list, table, results, side buffers) returns
+    to the card (tools/leak_probe.py runs the longer version)."""
+    import ctypes
+    capi = gpu["capi"]
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        assert hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0
+        return f.value
+
+    pts = gpu["shapes"].torus_random(1_000_000, seed=3)
+
+    def once(i):
+        h = capi.Handle(0)
+        h.set_points(pts if i % 2 else pts[:400_000])
+        h.set_query_range(0, 300_000 if i % 3 == 0 else h.n)
+        h.curvature(50, 0.0, capi.KNN_GRID if i % 4 else capi.KNN_GRID_LEVELS)
+        h.get_fit(0, 100); h.get_neighbors(0, 100)
+        h.query_points(pts[:3].astype(np.float64), 5)
+        h.voxel_downsample(pts[:50_000], 0.05)
+        h.close()
+
+    once(1)                                    # warm the allocator's own caches
+    before = free_bytes()
+    for i in range(30):
+        once(i)
+    assert before - free_bytes() < 256 * 2**20     # one handle holds about 0.7 GB here: a leak would show 30-fold
