@@ -601,6 +601,78 @@ __device__ __forceinline__ void fast_sort_sets(FastK<NSETS * R>& t, const SortLa
     if constexpr (SIZE < 64 * R) fast_sort_sets<R, NSETS, SIZE * 2>(t, c);
 }
 
+// ---------------------------------------------------------------------------
+// Equal keys inside the sorted list: the quantised key cannot order those elements, the exact values can.
+// On the reference's own generator output (theta x phi lattices, utils.py:883-914) every point has symmetric partners
+// whose squared distances differ by float32 rounding noise only -- most queries meet at least one pair of equal keys
+// among their first k+2 entries, and handing each of them to the wave-per-query exact sweep costs 10-50x the fast
+// path.  Instead the list is repaired in place: an odd-even transposition over the sorted list in which two
+// neighbours are compared -- by exact fp64 d2, then by public index, the total order of k_knn_exact -- ONLY when
+// their keys are equal.  Elements with different keys never move, so every run of equal keys ends up in the exact
+// order and everything proven on keys (the (k+1)-th key against the stencil radius, the pre-selection cut, eps)
+// stays proven.  Runs are short (2, 4 or 8 symmetric partners): two or three passes and a quiet round.
+//   exact_d2(payload)  fp64 squared distance of the element with that payload (LDS reads only; real elements only)
+//   pos_of(payload)    its sorted position; may use cross-lane reads: called with every lane active
+// Returns false when the list is still not in order after kOrderPasses (a long pile of equal keys): redo list.
+// ---------------------------------------------------------------------------
+constexpr int kOrderPasses = 36;
+
+template <int R, int SLOT_BITS, class ExactD2, class PosOf>
+__device__ __forceinline__ bool order_equal_keys(unsigned* e, const float4* __restrict__ pts, const ExactD2& exact_d2,
+                                                 const PosOf& pos_of) {
+    const int lane = lane_id();
+    constexpr unsigned PAYLOAD = (1u << SLOT_BITS) - 1u;
+    double d[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        d[r] = INFINITY;
+        if (e[r] != kPadElem) d[r] = exact_d2(e[r] & PAYLOAD);
+    }
+    int quiet = 0;
+#pragma unroll 1
+    for (int pass = 0; pass < kOrderPasses; ++pass) {
+        const int par = pass & 1;
+        const int pl = ((lane - par) ^ 1) + par;      // partner lane: -1 / 64 = last / first lane of the neighbouring register
+        const int addr = (pl & 63) << 2;
+        const int dr = pl >> 6;                       // -1, 0, +1: register of the partner relative to mine
+        unsigned be[R];
+        int blo[R], bhi[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            be[r] = (unsigned)__builtin_amdgcn_ds_bpermute(addr, (int)e[r]);
+            blo[r] = __builtin_amdgcn_ds_bpermute(addr, __double2loint(d[r]));
+            bhi[r] = __builtin_amdgcn_ds_bpermute(addr, __double2hiint(d[r]));
+        }
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int pr = r + dr;
+            unsigned pe = kPadElem;
+            double pd = INFINITY;
+#pragma unroll
+            for (int r2 = 0; r2 < R; ++r2)
+                if (pr == r2) { pe = be[r2]; pd = __hiloint2double(bhi[r2], blo[r2]); }
+            const bool same = pr >= 0 && pr < R && e[r] != kPadElem && pe != kPadElem && ((e[r] ^ pe) >> SLOT_BITS) == 0u;
+            bool p_lt_m = pd < d[r], m_lt_p = d[r] < pd;
+            const bool tie = same && pd == d[r];
+            if (__builtin_amdgcn_ballot_w64(tie) != 0ull) {       // exact tie somewhere: public indices decide
+                const int my_pos = pos_of(e[r] & PAYLOAD), p_pos = pos_of(pe & PAYLOAD);
+                if (tie) {
+                    const int mp = pub_index(pts, my_pos), pp = pub_index(pts, p_pos);
+                    p_lt_m = pp < mp;
+                    m_lt_p = mp < pp;
+                }
+            }
+            const bool take = same && (pl > lane ? p_lt_m : m_lt_p);     // the lower position keeps the smaller one
+            if (take) { e[r] = pe; d[r] = pd; }
+            any |= take;
+        }
+        if (__builtin_amdgcn_ballot_w64(any) != 0ull) quiet = 0;
+        else if (++quiet == 2) return true;
+    }
+    return false;
+}
+
 // waves per block of the fast sweep: chosen so that whole blocks fill the 160 KiB of LDS (waves are independent;
 // R = 1: 6 blocks x 4 waves x 6.25 KiB, R = 2: 4 blocks x 4 waves x 9.5 KiB)
 #ifndef PCT_FAST_WAVES
@@ -1021,6 +1093,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
             // ---- proof obligations per query (see the single-query path below) -----------------------------------------
             bool amb_a = false, amb_b = false, sparse_a = false, sparse_b = false;
+            bool col_a = false, col_b = false;        // equal keys among the first k+2 entries
             {
                 unsigned tau_a, tau_b;         // element k of each list = the (k+1)-th nearest (padding if fewer exist)
                 {
@@ -1055,12 +1128,59 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                         up_b = kPadElem;
                     }
                     const int i = lane + 64 * r;
-                    amb_a |= i <= k && both.e[r] != kPadElem && up_a != kPadElem && ((both.e[r] ^ up_a) >> SLOT_BITS) == 0u;
-                    amb_b |= i <= k && both.e[R + r] != kPadElem && up_b != kPadElem && ((both.e[R + r] ^ up_b) >> SLOT_BITS) == 0u;
+                    col_a |= i <= k && both.e[r] != kPadElem && up_a != kPadElem && ((both.e[r] ^ up_a) >> SLOT_BITS) == 0u;
+                    col_b |= i <= k && both.e[R + r] != kPadElem && up_b != kPadElem && ((both.e[R + r] ^ up_b) >> SLOT_BITS) == 0u;
                 }
             }
             if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a, sparse_a ? 1 : 3); ok_a = false; }
             if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b, sparse_b ? 1 : 3); ok_b = false; }
+            // equal keys: ordered here by the exact values (order_equal_keys), not by the exact sweep
+            const auto pos_of_set = [&](unsigned at, int set) {
+                int p = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
+#pragma unroll
+                for (int r2 = 1; r2 < R; ++r2) {
+                    const int p2 = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
+                    if ((int)(at >> 6) == r2) p = p2;
+                }
+                return p;
+            };
+            // (the query is fetched from its lane again: keeping the six coordinates of the pair alive across the sort
+            // for this rare branch would cost the common path scalar registers it does not have)
+            const auto query_of = [&](int ql, double& x, double& y, double& z) {
+                if constexpr (Q64) {
+                    x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.x), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.x), ql));
+                    y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.y), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.y), ql));
+                    z = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.z), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.z), ql));
+                } else {
+                    x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), ql));
+                    y = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), ql));
+                    z = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), ql));
+                }
+            };
+            if (ok_a && __ballot(col_a) != 0ull) {
+                double ux, uy, uz;
+                query_of(qi, ux, uy, uz);
+                const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[0], a.pts,
+                    [&](unsigned at) {
+                        const int j = (int)pend[at] & (CAP_POW2 - 1);
+                        const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
+                        return (dx * dx + dy * dy) + dz * dz;
+                    },
+                    [&](unsigned at) { return pos_of_set(at, 0); });
+                if (!done) { push_redo(row_a, 3); ok_a = false; }
+            }
+            if (ok_b && __ballot(col_b) != 0ull) {
+                double ux, uy, uz;
+                query_of(qj, ux, uy, uz);
+                const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[R], a.pts,
+                    [&](unsigned at) {
+                        const int j = (int)pend_b[at] & (CAP_POW2 - 1);
+                        const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
+                        return (dx * dx + dy * dy) + dz * dz;
+                    },
+                    [&](unsigned at) { return pos_of_set(at, 1); });
+                if (!done) { push_redo(row_b, 3); ok_b = false; }
+            }
             // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
 #pragma unroll
             for (int set = 0; set < 2; ++set) {
@@ -1115,6 +1235,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
 
         FastK<R> best;
         bool amb = false;                    // per-lane: something this kernel cannot prove exact
+        bool col = false;                    // per-lane: equal keys among the first k+2 entries
         unsigned bkey = 0xFFFFFFFFu;         // exact keys of the candidates the pre-selection cut are >= bkey
         if constexpr (PRE) {
             const float fqx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
@@ -1320,12 +1441,39 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
                     up = kPadElem;
                 }
                 const int i = lane + 64 * r;
-                amb |= i <= k && best.e[r] != kPadElem && up != kPadElem && ((best.e[r] ^ up) >> SLOT_BITS) == 0u;
+                col |= i <= k && best.e[r] != kPadElem && up != kPadElem && ((best.e[r] ^ up) >> SLOT_BITS) == 0u;
             }
         }
         if (__ballot(amb) != 0ull) {
             note_redo(row, sparse ? 1 : 3);
             continue;
+        }
+        // sorted position of staged slot j = j + offset of its run (cross-lane reads: every lane active)
+        const auto slot_pos = [&](int j) {
+            unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+            if constexpr ((CAP / 64 + 7) / 8 > 1) {
+                const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
+                code = (j >> 9) ? hi : code;
+            }
+            return j + offc[(code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u];
+        };
+        if (__ballot(col) != 0ull) {      // equal keys: ordered here by the exact values, not by the exact sweep
+            const auto slot_of = [&](unsigned at) {
+                int j = (int)at;
+                if constexpr (PRE) j = (int)pend[j] & (CAP_POW2 - 1);
+                return j;
+            };
+            const bool done = order_equal_keys<R, SLOT_BITS>(&best.e[0], a.pts,
+                [&](unsigned at) {
+                    const int j = slot_of(at);
+                    const double dx = (double)cand_x[j] - qx, dy = (double)cand_y[j] - qy, dz = (double)cand_z[j] - qz;
+                    return (dx * dx + dy * dy) + dz * dz;
+                },
+                [&](unsigned at) { return slot_pos(slot_of(at) & (CAP_POW2 - 1)); });
+            if (!done) {
+                note_redo(row, 3);
+                continue;
+            }
         }
 
         // ---- store: exact fp64 distance re-derived from the coordinates -------

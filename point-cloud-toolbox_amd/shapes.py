@@ -79,10 +79,21 @@ def torus_scan_order(n, parts, part, seed=1234, R=TORUS_R, r=TORUS_r, dtype=np.f
 
 
 def torus_grid(n_side, R=TORUS_R, r=TORUS_r, dtype=np.float32):
-    """Reference-style theta x phi lattice (utils.py:888-896); many k-NN ties."""
-    t = np.linspace(0.0, 2.0 * np.pi, n_side)
+    """The reference's own torus (utils.py:883-896 generate_torus_points with num_points = n_side^2, so that no
+    rows are re-drawn): theta x phi lattice, ``linspace(0, 2 pi, n_side, endpoint=False)`` on both axes, phi-major
+    row order (``meshgrid`` then ``ravel``).  Every point has symmetric partners at (nearly) equal distances."""
+    t = np.linspace(0.0, 2.0 * np.pi, n_side, endpoint=False)
     th, ph = np.meshgrid(t, t)
     return torus_from_angles(np.stack([th.ravel(), ph.ravel()], 1), R, r, dtype)
+
+
+def egg_carton_grid(n_side, amp=0.1, dtype=np.float32):
+    """The reference's own egg carton (utils.py:906-914 generate_egg_carton_points, num_points = n_side^2):
+    [-1, 1]^2 lattice with both end points, z = amp sin(pi x) cos(pi y)."""
+    t = np.linspace(-1.0, 1.0, n_side)
+    X, Y = np.meshgrid(t, t)
+    Z = amp * np.sin(X * np.pi) * np.cos(Y * np.pi)
+    return np.stack([X.ravel(), Y.ravel(), Z.ravel()], 1).astype(dtype)
 
 
 def egg_carton_random(n, seed=1234, amp=0.1, dtype=np.float32, lo=0, hi=None, with_truth=False):
