@@ -64,6 +64,8 @@ typedef struct pct_timings {
                                  the part kept                                            */
     int32_t levels;           /* passes of the density-adaptive sweep (0 = not used)       */
     double occupancy;         /* mean number of points sharing a point's cell (the cell-size search steers on it) */
+    int64_t fit_svd_rows;     /* rows of the last fit solved by the SVD kernel (lstsq's gelsd semantics: ill-conditioned
+                                 or under-determined design matrices) instead of the normal equations */
 } pct_timings;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -37,6 +37,7 @@ class Timings(C.Structure):
         ("cell_size", C.c_double),
         ("grid_points", C.c_int64), ("limit_retries", C.c_int32), ("levels", C.c_int32),
         ("occupancy", C.c_double),
+        ("fit_svd_rows", C.c_int64),
     ]
 
     def as_dict(self):

@@ -51,7 +51,16 @@ struct FitArgs {
     double* coefs64;         // diagnostics variant (OUT64): unrounded coefficients and float64 curvatures, row-aligned
     double* K64;
     double* H64;
+    int* flag_list;          // rows k_fit hands to k_fit_svd (ill-conditioned or under-determined design matrices)
+    int* flag_count;
+    unsigned n_pts;          // records in pts: a table entry outside [0, n_pts) is never dereferenced (the row reads NaN)
 };
+
+// Smallest Cholesky pivot ratio d_j / g_jj (= sin^2 of the angle between design column j and the span of the columns
+// before it; invariant under column scaling) below which the normal equations are not trusted.  Their error grows like
+// eps / ratio: measured against LAPACK's gelsd on anisotropic lattices (tools notes in DESIGN 4.3), ratios >= 1e-9 stay
+// at float32 rounding noise (<= 2.4e-7 relative in K, H), [1e-10, 1e-9) reach 1.3e-5.  1e-6 leaves three decades.
+constexpr double kPivotRatioMin = 1e-6;
 
 // One Jacobi rotation annihilating a_pq of a symmetric 3x3 (r = third index).
 // With alpha = (a_qq - a_pp)/2 and beta = a_pq the tangent of the rotation is
@@ -163,7 +172,9 @@ __device__ __forceinline__ void plane_rotation(int m, double sx, double sy, doub
     rot[0] = r00; rot[1] = r01; rot[2] = r02; rot[3] = r10; rot[4] = r11; rot[5] = r12; rot[6] = r20; rot[7] = r21; rot[8] = r22;
 }
 
-template <bool F64, bool OUT64 = false>
+// STAGED = false: rows too long for the LDS staging area (k > 255, only reachable through caller-supplied rows:
+// pct_fit_indices takes any k the reference's fit would) are walked in global memory instead.
+template <bool F64, bool OUT64 = false, bool STAGED = true>
 __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     extern __shared__ int s_idx[];   // 64 rows x kp
     const int lane = threadIdx.x;
@@ -173,7 +184,7 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     // ---- stage 64 index rows: 16 lanes x int4 per row, 4 rows per load instruction, all loads independent
     // (rows are 16-byte aligned: pitch is a multiple of 4) -------------------------------------------------
     const int nrow = (int)min((int64_t)kFitBlock, a.rows - row0);
-    {
+    if constexpr (STAGED) {
         const int sub = lane >> 4, c4 = (lane & 15) << 2;
         for (int cb = 0; cb < k; cb += 64) {
             const int c = cb + c4;
@@ -207,10 +218,19 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         qx = qd.x; qy = qd.y; qz = qd.z;
     }
     const int m = a.cnt ? a.cnt[row] : k;
-    const int* my = s_idx + lane * kp;
+    const int* my = STAGED ? s_idx + lane * kp : a.table + row * a.pitch;
     const float nanf_ = __int_as_float(0x7fc00000);
 
-    if (m < 6) {   // under-determined quadric (only reachable through the eps bound)
+    // rows this kernel does not finish go to k_fit_svd: one counter increment per wave
+    const auto hand_over = [&]() {
+        const unsigned long long fm = __ballot(1);                  // the lanes that are here together
+        const int leader = (int)__builtin_ctzll(fm);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(a.flag_count, (int)__popcll(fm));
+        base = __shfl(base, leader);
+        a.flag_list[base + (int)__popcll(fm & ((1ull << lane) - 1ull))] = (int)row;
+    };
+    if (m < 6) {   // under-determined quadric (eps bound, neighbour study): lstsq's minimum-norm answer, k_fit_svd
         if constexpr (OUT64) {
             for (int j = 0; j < 6; ++j) a.coefs64[out * 6 + j] = (double)nanf_;
             a.K64[out] = (double)nanf_; a.H64[out] = (double)nanf_;
@@ -218,6 +238,7 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
             for (int j = 0; j < 6; ++j) a.coefs[out * 6 + j] = nanf_;
             a.K[out] = nanf_; a.H[out] = nanf_; a.H2[out] = nanf_;
         }
+        if (m >= 2) hand_over();       // (np.cov of fewer than two points is NaN in the reference as well)
         return;
     }
 
@@ -231,12 +252,20 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);           \
         syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);           \
     } while (0)
+    // A table entry that is not a record of the cloud (host-supplied rows are validated before they get here, the
+    // sweep's rows are the sweep's responsibility: this is the last line of defence) is clamped, never dereferenced,
+    // and the row reads NaN.
+    bool bad_id = false;
+    const auto checked = [&](int id) {
+        bad_id |= (unsigned)id >= a.n_pts;
+        return (int)min((unsigned)id, a.n_pts - 1u);
+    };
     {
         int j = 0;
         for (; j + 8 <= m; j += 8) {
             double x[8], y[8], z[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) load_centred<F64>(a, my[j + u], qx, qy, qz, qp.x, qp.y, qp.z, x[u], y[u], z[u]);
+            for (int u = 0; u < 8; ++u) load_centred<F64>(a, checked(my[j + u]), qx, qy, qz, qp.x, qp.y, qp.z, x[u], y[u], z[u]);
             if (j == 0) { fx = x[0]; fy = y[0]; fz = z[0]; }
 #pragma unroll
             for (int u = 0; u < 8; ++u) PASS1_ACC(x[u], y[u], z[u]);
@@ -244,13 +273,23 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         }
         for (; j < m; ++j) {
             double x, y, z;
-            load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+            load_centred<F64>(a, checked(my[j]), qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
             if (j == 0) { fx = x; fy = y; fz = z; }
             PASS1_ACC(x, y, z);
             lx = x; ly = y; lz = z;
         }
     }
 #undef PASS1_ACC
+    if (bad_id) {
+        if constexpr (OUT64) {
+            for (int j = 0; j < 6; ++j) a.coefs64[out * 6 + j] = (double)nanf_;
+            a.K64[out] = (double)nanf_; a.H64[out] = (double)nanf_;
+        } else {
+            for (int j = 0; j < 6; ++j) a.coefs[out * 6 + j] = nanf_;
+            a.K[out] = nanf_; a.H[out] = nanf_; a.H2[out] = nanf_;
+        }
+        return;
+    }
     double rot[9];
     plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
     const double r00 = rot[0], r01 = rot[1], r02 = rot[2], r10 = rot[3], r11 = rot[4], r12 = rot[5], r20 = rot[6], r21 = rot[7], r22 = rot[8];
@@ -305,12 +344,14 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     // packed index of (i,j), j<=i : i*(i+1)/2 + j
 #define GI(i, j) ((i) * ((i) + 1) / 2 + (j))
     double dinv[6];                 // 1 / L_jj
+    bool well = true;               // every pivot ratio d_j / g_jj above kPivotRatioMin: the columns are far from dependent
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         double d = g[GI(j, j)];
 #pragma unroll
         for (int p = 0; p < j; ++p) d -= g[GI(j, p)] * g[GI(j, p)];
-        const double inv = rsqrt(d);                    // NaN for a non-positive pivot (degenerate neighbourhood)
+        well = well && d > kPivotRatioMin * g[GI(j, j)];               // (false for NaN and for an all-zero column too)
+        const double inv = rsqrt(d);                    // NaN for a non-positive pivot: such rows are handed over
         dinv[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < 6; ++i) {
@@ -335,6 +376,10 @@ __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
         b[i] = s * dinv[i];
     }
 #undef GI
+    // An ill-conditioned design matrix (neighbours on a line or a planar curve, anisotropic lattices, duplicates): the
+    // reference's lstsq (pct:359) is LAPACK gelsd -- an SVD-based solve with the singular values below
+    // eps * max(m, 6) * sigma_1 cut off -- whose answer the normal equations cannot follow.  k_fit_svd redoes the row.
+    if (!well) hand_over();
     if constexpr (OUT64) {
         // diagnostics: what the float32 rounding of the coefficients (pct:359) and the float32 curvature arithmetic
         // (pct:403-422) cost -- the solution as solved, and the same formulas in float64
@@ -372,113 +417,174 @@ __global__ __launch_bounds__(256) void k_curv(const float* __restrict__ coefs, i
 }
 
 // ---------------------------------------------------------------------------
-// Under-determined neighbourhoods (2 <= m <= 5 points): numpy.linalg.lstsq
-// (pct:359) returns the minimum-norm solution of the float32 design system.
-// Reached only by explicit_quadratic_neighbor_study (pct:759: n+1 points with
-// n >= 3).  Householder QR of X^T (6 x m) in registers, c = Q R^-T z, no column
-// scaling (scaling would change the norm that is minimised).
+// numpy.linalg.lstsq(X, z, rcond=None) (pct:359) for the rows k_fit handed over: float32 design rows widened to
+// float64, LAPACK gelsd semantics -- the least-squares solution through the singular value decomposition of X, with
+// the singular values sigma_i <= eps * max(m, 6) * sigma_1 treated as zero (eps = 2^-52: NumPy takes the machine
+// epsilon of the float64 COMPUTE type, also for float32 input), i.e. the minimum-norm solution of a rank-deficient
+// system -- and the result rounded to float32.
+//   1. the m x 6 design matrix is never stored: its rows are folded one by one into the 6 x 6 triangular factor R
+//      and the rotated right-hand side y by Givens rotations (X = Q R, y = Q^T z: what gelsd's first QR step yields,
+//      and no squaring of the condition number as in the normal equations);
+//   2. one-sided Jacobi on R: R V = U Sigma, singular values with high relative accuracy;
+//   3. c = V Sigma^+ U^T y over the singular values above the cut-off.
+// One thread per listed row; the list length is read on the device (no host round trip), the grid is fixed.
 // ---------------------------------------------------------------------------
-template <bool F64>
-__global__ __launch_bounds__(64) void k_fit_minnorm(FitArgs a) {
-    const int64_t row = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (row >= a.rows) return;
-    const int m = a.cnt[row];
-    if (m >= 6) return;                       // handled by k_fit
-    const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
-    const float4 qp = a.pts[qid];
-    double qx = qp.x, qy = qp.y, qz = qp.z;
-    if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
-    const int* my = a.table + row * a.pitch;
+template <bool F64, bool OUT64>
+__global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict__ list, const int* __restrict__ list_count,
+                                                long long* __restrict__ host_count) {
+    const int total = *list_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = total;           // pinned host word: read at the caller's next synchronisation
     const float nanf_ = __int_as_float(0x7fc00000);
-    float* co = a.coefs + row * 6;
-    if (m < 2) {
-        for (int j = 0; j < 6; ++j) co[j] = nanf_;
-        a.K[row] = nanf_; a.H[row] = nanf_; a.H2[row] = nanf_;
-        return;
-    }
-    double px[5], py[5], pz[5];
-    double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-    double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        px[j] = py[j] = pz[j] = 0;
-        if (j < m) {
-            load_centred<F64>(a, my[j], qx, qy, qz, qp.x, qp.y, qp.z, px[j], py[j], pz[j]);
-            const double x = px[j], y = py[j], z = pz[j];
+    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 64) {
+        const int64_t row = list[it];
+        const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
+        const float4 qp = a.pts[qid];
+        const int64_t out = a.out_by_row ? row : (int64_t)__float_as_int(qp.w) - a.out_base;
+        double qx = qp.x, qy = qp.y, qz = qp.z;
+        if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
+        const int m = a.cnt ? a.cnt[row] : a.k;
+        const int* my = a.table + row * a.pitch;
+
+        // ---- pass 1: moments -> tangent-plane rotation (as k_fit) ----------------------------------------------
+        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
+        for (int j = 0; j < m; ++j) {
+            double x, y, z;
+            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
             if (j == 0) { fx = x; fy = y; fz = z; }
             lx = x; ly = y; lz = z;
             sx += x; sy += y; sz += z;
             sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
             syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
         }
-    }
-    double rot[9];
-    plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
-    // A = X^T: column j = design row of neighbour j (float32 entries, pct:358)
-    double A[5][6], zv[5];
+        double rot[9];
+        plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
+
+        // ---- pass 2: Givens QR of the design rows, row by row -------------------------------------------------
+        double A[6][6];        // A[c][r]: column c of the triangular factor (rows r <= c in use), later R V
+        double y[6];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        const float pa = (float)((rot[0] * px[j] + rot[1] * py[j]) + rot[2] * pz[j]);
-        const float pb = (float)((rot[3] * px[j] + rot[4] * py[j]) + rot[5] * pz[j]);
-        const float pc = (float)((rot[6] * px[j] + rot[7] * py[j]) + rot[8] * pz[j]);
-        const bool v = j < m;
-        A[j][0] = v ? (double)(pa * pa) : 0.0; A[j][1] = v ? (double)(pb * pb) : 0.0; A[j][2] = v ? (double)(pa * pb) : 0.0;
-        A[j][3] = v ? (double)pa : 0.0;        A[j][4] = v ? (double)pb : 0.0;        A[j][5] = v ? 1.0 : 0.0;
-        zv[j] = v ? (double)pc : 0.0;
-    }
-    // Householder QR, column by column; reflector j acts on components j..5
-    double beta[5], rdiag[5];
+        for (int c = 0; c < 6; ++c) {
+            y[c] = 0;
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
-        double nrm2 = 0;
+            for (int r = 0; r < 6; ++r) A[c][r] = 0;
+        }
+#pragma unroll 1
+        for (int j = 0; j < m; ++j) {
+            double px, py, pz;
+            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, px, py, pz);
+            const float pa = (float)((rot[0] * px + rot[1] * py) + rot[2] * pz);
+            const float pb = (float)((rot[3] * px + rot[4] * py) + rot[5] * pz);
+            const float pc = (float)((rot[6] * px + rot[7] * py) + rot[8] * pz);
+            double x[6] = {(double)(pa * pa), (double)(pb * pb), (double)(pa * pb), (double)pa, (double)pb, 1.0};   // pct:358
+            double zi = (double)pc;
 #pragma unroll
-        for (int i = j; i < 6; ++i) nrm2 = fma(A[j][i], A[j][i], nrm2);
-        const double nrm = sqrt(nrm2);
-        const double alpha = A[j][j] > 0 ? -nrm : nrm;
-        rdiag[j] = alpha;
-        A[j][j] -= alpha;                                   // v = x - alpha e1 (stored in place)
-        double vv = 0;
+            for (int r = 0; r < 6; ++r) {
+                const double xr = x[r];
+                if (xr != 0.0) {
+                    const double rr = A[r][r];
+                    const double h = sqrt(rr * rr + xr * xr);
+                    const double inv = 1.0 / h;
+                    const double c = rr * inv, sn = xr * inv;
+                    A[r][r] = h;
 #pragma unroll
-        for (int i = j; i < 6; ++i) vv = fma(A[j][i], A[j][i], vv);
-        beta[j] = vv > 0 ? 2.0 / vv : 0.0;
+                    for (int c2 = r + 1; c2 < 6; ++c2) {
+                        const double t = A[c2][r];
+                        A[c2][r] = c * t + sn * x[c2];
+                        x[c2] = c * x[c2] - sn * t;
+                    }
+                    const double t = y[r];
+                    y[r] = c * t + sn * zi;
+                    zi = c * zi - sn * t;
+                }
+            }
+        }
+
+        // ---- one-sided Jacobi: rotate the columns of A (and of V) until they are mutually orthogonal ------------
+        double V[6][6];        // V[c][r]: column c
 #pragma unroll
-        for (int c = j + 1; c < 5; ++c) {
-            double dotp = 0;
+        for (int c = 0; c < 6; ++c)
 #pragma unroll
-            for (int i = j; i < 6; ++i) dotp = fma(A[j][i], A[c][i], dotp);
-            const double f = beta[j] * dotp;
+            for (int r = 0; r < 6; ++r) V[c][r] = c == r ? 1.0 : 0.0;
+#pragma unroll 1
+        for (int sweep = 0; sweep < 40; ++sweep) {
+            bool rotated = false;
 #pragma unroll
-            for (int i = j; i < 6; ++i) A[c][i] -= f * A[j][i];
+            for (int p = 0; p < 5; ++p) {
+#pragma unroll
+                for (int q = p + 1; q < 6; ++q) {
+                    double al = 0, be = 0, ga = 0;
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) {
+                        al = fma(A[p][r], A[p][r], al);
+                        be = fma(A[q][r], A[q][r], be);
+                        ga = fma(A[p][r], A[q][r], ga);
+                    }
+                    if (ga != 0.0 && fabs(ga) > 1e-15 * sqrt(al * be)) {
+                        rotated = true;
+                        const double zeta = (be - al) / (2.0 * ga);
+                        const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                        const double c = rsqrt(1.0 + t * t), sn = c * t;
+#pragma unroll
+                        for (int r = 0; r < 6; ++r) {
+                            const double ap = A[p][r], aq = A[q][r];
+                            A[p][r] = c * ap - sn * aq;
+                            A[q][r] = sn * ap + c * aq;
+                            const double vp = V[p][r], vq = V[q][r];
+                            V[p][r] = c * vp - sn * vq;
+                            V[q][r] = sn * vp + c * vq;
+                        }
+                    }
+                }
+            }
+            if (!__any(rotated)) break;
+        }
+        // ---- c = V Sigma^+ U^T y, U_c = A_c / sigma_c; cut-off as gelsd (rcond = eps max(m, 6)) ----------------
+        double sig2[6], smax2 = 0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            double t = 0;
+#pragma unroll
+            for (int r = 0; r < 6; ++r) t = fma(A[c][r], A[c][r], t);
+            sig2[c] = t;
+            smax2 = fmax(smax2, t);
+        }
+        const double rcond = 2.220446049250313e-16 * (double)(m > 6 ? m : 6);
+        const double cut = rcond * sqrt(smax2);
+        double sol[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            if (sqrt(sig2[c]) > cut) {
+                double t = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r) t = fma(A[c][r], y[r], t);
+                const double w = t / sig2[c];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) sol[r] = fma(V[c][r], w, sol[r]);
+            }
+        }
+        if (m < 2) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) sol[r] = (double)nanf_;
+        }
+        if constexpr (OUT64) {
+            double* co64 = a.coefs64 + out * 6;
+            for (int j = 0; j < 6; ++j) co64[j] = sol[j];
+            const double Fx = sol[3], Fy = sol[4], Fxx = 2.0 * sol[0], Fyy = 2.0 * sol[1], Fxy = sol[2];
+            const double wgt = (1.0 + Fx * Fx) + Fy * Fy;
+            a.K64[out] = (Fxx * Fyy - Fxy * Fxy) / (wgt * wgt);
+            a.H64[out] = (((1.0 + Fx * Fx) * Fyy - ((2.0 * Fx) * Fy) * Fxy) + (1.0 + Fy * Fy) * Fxx) / (2.0 * (wgt * sqrt(wgt)));
+        } else {
+            const float Af = (float)sol[0], Bf = (float)sol[1], Cf = (float)sol[2], Df = (float)sol[3], Ef = (float)sol[4];
+            float* co = a.coefs + out * 6;
+            co[0] = Af; co[1] = Bf; co[2] = Cf; co[3] = Df; co[4] = Ef; co[5] = (float)sol[5];
+            float Kg, Kh;
+            monge_curvatures(Af, Bf, Cf, Df, Ef, Kg, Kh);
+            a.K[out] = Kg;
+            a.H[out] = Kh;
+            a.H2[out] = Kh * Kh;
         }
     }
-    // R^T y = z  (R upper triangular: R[p][c] = A[c][p] for p < c, diagonal rdiag)
-    double y[6] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 5; ++c) {
-        double sacc = zv[c];
-#pragma unroll
-        for (int p2 = 0; p2 < c; ++p2) sacc -= A[c][p2] * y[p2];
-        y[c] = c < m ? sacc / rdiag[c] : 0.0;
-    }
-    // c = Q [y; 0]: reflectors in reverse order
-#pragma unroll
-    for (int j = 4; j >= 0; --j) {
-        if (j < m) {
-            double dotp = 0;
-#pragma unroll
-            for (int i = j; i < 6; ++i) dotp = fma(A[j][i], y[i], dotp);
-            const double f = beta[j] * dotp;
-#pragma unroll
-            for (int i = j; i < 6; ++i) y[i] -= f * A[j][i];
-        }
-    }
-    const float Af = (float)y[0], Bf = (float)y[1], Cf = (float)y[2], Df = (float)y[3], Ef = (float)y[4];
-    co[0] = Af; co[1] = Bf; co[2] = Cf; co[3] = Df; co[4] = Ef; co[5] = (float)y[5];
-    float Kg, Kh;
-    monge_curvatures(Af, Bf, Cf, Df, Ef, Kg, Kh);
-    a.K[row] = Kg;
-    a.H[row] = Kh;
-    a.H2[row] = Kh * Kh;
 }
 
 // explicit_quadratic_neighbor_study (pct:756-761): row (s, n) = the sample point itself followed by its n nearest
@@ -521,18 +627,40 @@ __global__ __launch_bounds__(256) void k_gather_fit(const int* __restrict__ row_
 int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     FitArgs a = a0;
     a.kp = a.k | 1;
-    const size_t lds = (size_t)kFitBlock * a.kp * sizeof(int);
+    size_t lds = (size_t)kFitBlock * a.kp * sizeof(int);
+    const bool staged = lds <= 64 * 1024;                  // the default dynamic LDS limit of a launch
+    if (!staged) lds = 0;
     const int blocks = (int)((a.rows + kFitBlock - 1) / kFitBlock);
     if (blocks <= 0) return PCT_OK;
+    // rows for k_fit_svd: list + its length (first word of the buffer's 64-byte head)
+    PCT_TRY(pct_reserve(ctx, &ctx->fit_flag, 64 + (size_t)a.rows * sizeof(int)));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->fit_flag.p, 0, 64, ctx->stream));
+    a.flag_count = (int*)ctx->fit_flag.p;
+    a.flag_list = (int*)ctx->fit_flag.p + 16;
+#define PCT_FIT_LAUNCH(F_, O_)                                                                                      \
+    do {                                                                                                            \
+        if (staged) hipLaunchKernelGGL((k_fit<F_, O_, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);  \
+        else hipLaunchKernelGGL((k_fit<F_, O_, false>), dim3(blocks), dim3(kFitBlock), 0, ctx->stream, a);          \
+    } while (0)
+    if (a.coefs64) {
+        if (f64) PCT_FIT_LAUNCH(true, true);
+        else PCT_FIT_LAUNCH(false, true);
+    } else if (f64) PCT_FIT_LAUNCH(true, false);
+    else PCT_FIT_LAUNCH(false, false);
+#undef PCT_FIT_LAUNCH
+    PCT_HIP(ctx, hipGetLastError());
+    // the rows handed over: fixed grid, the list length is read on the device
+    const int sblocks = blocks < 1024 ? blocks : 1024;
+    long long* note = (long long*)(ctx->pin + 256);
     if (a.coefs64) {
         if (f64)
-            hipLaunchKernelGGL((k_fit<true, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+            hipLaunchKernelGGL((k_fit_svd<true, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
         else
-            hipLaunchKernelGGL((k_fit<false, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+            hipLaunchKernelGGL((k_fit_svd<false, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     } else if (f64)
-        hipLaunchKernelGGL((k_fit<true, false>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_fit_svd<true, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     else
-        hipLaunchKernelGGL((k_fit<false, false>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);
+        hipLaunchKernelGGL((k_fit_svd<false, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -570,6 +698,7 @@ int pct_launch_fit_table(pct_ctx* ctx) {
     a.K = (float*)ctx->K.p;
     a.H = (float*)ctx->H.p;
     a.H2 = (float*)ctx->H2.p;
+    a.n_pts = (unsigned)(sorted ? ctx->n_grid : ctx->n);
     return launch(ctx, a, ctx->has_f64);
 }
 
@@ -584,7 +713,7 @@ int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_co
 // fit from explicit neighbour rows, outputs row-aligned.  sorted_space: ids refer to the cell-sorted arrays.
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query,
                         int64_t rows, int32_t k, int32_t pitch, float* d_coefs, float* d_K, float* d_H, float* d_H2,
-                        bool sorted_space, bool minnorm_pass) {
+                        bool sorted_space) {
     FitArgs a = {};
     a.pts = (const float4*)(sorted_space ? ctx->sorted4.p : ctx->pts4.p);
     a.ptsd = ctx->has_f64 ? (const double4*)(sorted_space ? ctx->sorted4d.p : ctx->pts4d.p) : nullptr;
@@ -602,16 +731,9 @@ int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt
     a.K = d_K;
     a.H = d_H;
     a.H2 = d_H2;
-    PCT_TRY(launch(ctx, a, ctx->has_f64));
-    if (minnorm_pass && d_cnt) {              // rows with fewer than 6 points: minimum-norm lstsq (overwrites the NaNs)
-        const int blocks = (int)((rows + 63) / 64);
-        if (ctx->has_f64)
-            hipLaunchKernelGGL(k_fit_minnorm<true>, dim3(blocks), dim3(64), 0, ctx->stream, a);
-        else
-            hipLaunchKernelGGL(k_fit_minnorm<false>, dim3(blocks), dim3(64), 0, ctx->stream, a);
-        PCT_HIP(ctx, hipGetLastError());
-    }
-    return PCT_OK;
+    a.n_pts = (unsigned)(sorted_space ? ctx->n_grid : ctx->n);
+    // (rows with fewer than 6 points get lstsq's minimum-norm answer from k_fit_svd, as in every launch)
+    return launch(ctx, a, ctx->has_f64);
 }
 
 // the diagnostics variant of pct_launch_fit_rows: float64 coefficients and curvatures, public-space ids
@@ -633,6 +755,7 @@ int pct_launch_fit_rows_f64(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d
     a.coefs64 = d_coefs;
     a.K64 = d_K;
     a.H64 = d_H;
+    a.n_pts = (unsigned)ctx->n;
     return launch(ctx, a, ctx->has_f64);
 }
 

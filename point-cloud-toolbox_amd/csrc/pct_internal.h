@@ -100,7 +100,7 @@ struct pct_ctx {
     pct_buf red;        // small reduction scratch
     // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
     // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
-    // [192,256) sweep counters
+    // [192,256) sweep counters  [256,264) rows of the last fit that went to k_fit_svd
     unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;
@@ -126,6 +126,7 @@ struct pct_ctx {
     bool fit_cloud_aligned = false;// results belong to cloud rows [q_begin, q_end) (pct_fit / pct_curvature) rather than to the
                                    // rows of a pct_fit_indices call; kept apart from knn_valid, which helpers may clear
 
+    pct_buf fit_flag;   // int: [0] number of rows k_fit handed to k_fit_svd, [16..] the rows
     // staging for downloads / host-index fits
     pct_buf stage_a, stage_b, stage_c, stage_d;
     pct_buf qpts4;      // float4 {x,y,z,index} of EVERY point in public order, for pct_query_points (built on first use)
@@ -189,7 +190,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
 int pct_launch_fit_table(pct_ctx* ctx);
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt,
                         const int64_t* d_query, int64_t rows, int32_t k, int32_t pitch,
-                        float* d_coefs, float* d_K, float* d_H, float* d_H2, bool sorted_space, bool minnorm_pass);
+                        float* d_coefs, float* d_K, float* d_H, float* d_H2, bool sorted_space);
 int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samples, int n_lo, int n_hi, int* d_table,
                            int pitch, int* d_cnt, int64_t* d_row_query);
 int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2);

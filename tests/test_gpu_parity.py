@@ -107,6 +107,99 @@ def test_unit_neighbourhood_branches(gpu, golden):
     h.close()
 
 
+# ---------------------------------------------- ill-conditioned / rank-deficient neighbourhoods (lstsq = gelsd, pct:359)
+def _design_diagnostics(P, i, nb):
+    """Singular values of the reference's design matrix of one neighbourhood (relative to the largest) and the
+    orientation test's dot product (pct:293): what decides whether the reference's own answer is well defined."""
+    q = P[nb] - P[i]
+    cov = np.cov(q, rowvar=False)
+    n = np.linalg.svd(cov)[2][-1]
+    ref = q[-1] - q[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        dot = np.dot(n / np.linalg.norm(n), ref / np.linalg.norm(ref))
+    p = np.array(oracle.plane_align(q), dtype=np.float32)
+    a, b = p[:, 0], p[:, 1]
+    X = np.column_stack((a ** 2, b ** 2, a * b, a, b, np.ones_like(a))).astype(np.float32).astype(np.float64)
+    s = np.linalg.svd(X, compute_uv=False)
+    return s / s[0], dot
+
+
+def test_degenerate_unit_neighbourhoods(gpu, golden):
+    """G6b: what the unmodified reference returns for collinear points, a planar curve, repeated points and
+    under-determined neighbourhoods -- gelsd cuts the singular values below eps max(m,6) sigma_1 and returns the
+    minimum-norm solution (pct:359); the kernel's SVD path (k_fit_svd) does the same."""
+    g = golden("g6b_degenerate_unit_cases.npz")
+    h = gpu["capi"].Handle(0)
+    for n in sorted(k[:-3] for k in g if k.endswith("_in")):
+        nb = g[n + "_in"]
+        cloud = np.vstack([np.zeros((1, 3), nb.dtype), nb])
+        h.set_points(cloud)
+        h.fit_indices(np.arange(1, len(cloud), dtype=np.int32)[None, :], query=np.array([0]))
+        co, K, H, _ = h.get_fit(0, 1)
+        ref_c, ref = g[n + "_coefs"], g[n + "_curv"]
+        assert np.isfinite(co).all() and np.isfinite(K[0]) and np.isfinite(H[0]), n
+        if n == "line_noise1e6":
+            # a singular value sits AT the cut-off (sigma_6 / sigma_1 ~ 1e-15 vs 6.7e-15): whether LAPACK keeps it is
+            # decided by its rounding -- the reference's answer is not a function of the input here.  Finite, no more.
+            continue
+        if n == "line_oblique":
+            # collinear up to float64 rounding: the right-hand side is rounding noise (1e-18), the answer noise / sigma
+            assert np.abs(co[0]).max() < 1e-5 and abs(K[0]) < 1e-8 and abs(H[0]) < 1e-5, n
+            continue
+        scale = max(1.0, float(np.abs(ref_c[:3]).max()))
+        assert np.allclose(co[0], ref_c, rtol=1e-5, atol=2e-6 * scale), (n, co[0], ref_c)
+        assert abs(K[0] - ref[0]) <= 1e-5 * max(abs(ref[0]), 1e-2 * scale * scale), n
+        assert abs(H[0] - ref[1]) <= 1e-5 * max(abs(ref[1]), 1e-2 * scale), n
+        if n != "six_points_x5":
+            assert h.timings()["fit_svd_rows"] == 1, n          # these are the rows the normal equations cannot do
+    h.close()
+
+
+@pytest.mark.parametrize("tag", ["plane_1to20", "cyl_1to20", "wavy_1to20", "wavy_1to4", "wavy_1to4_jitter"])
+def test_scan_line_clouds_against_the_reference(gpu, golden, tag):
+    """G10: clouds sampled densely along scan lines and sparsely across (0.005 x 0.1 / 0.02, k = 30: every
+    neighbourhood of the 1 : 20 clouds lies on ONE line), run through the whole reference class.  Row classes:
+      stable   no singular value of the design matrix within 100x of gelsd's cut-off and the kept ones above 1e-6
+               sigma_1: the usual 1e-5 contract;
+      noisy    kept singular values below 1e-6 sigma_1: the reference's own answer moves by more than 1e-5 when its
+               input moves by an ulp (condition^2 x eps x residual): compared at 1e-3;
+      band     a singular value within 100x of the cut-off: whether LAPACK keeps it is decided by rounding: finite only;
+      and where the orientation test's dot product (pct:293) is zero or rounding noise, the sign of the normal is
+      LAPACK's arbitrary sign of Vt[-1]: H is compared up to sign."""
+    g = golden(f"g10_scanline_{tag}_k30.npz")
+    P, k = g["points"], int(g["k"])
+    h = gpu["capi"].Handle(0)
+    h.set_points(P)
+    h.knn(k, 0.0, gpu["capi"].KNN_GRID)
+    idx, dist, _ = h.get_neighbors(0, len(P))
+    assert np.array_equal(dist, g["dists"])                       # (index rows differ inside the lattice's exact ties)
+    h.fit_indices(g["idx"])                                       # the reference's own neighbourhoods, every row
+    co, K, H, _ = h.get_fit(0, len(P))
+    svd_rows = h.timings()["fit_svd_rows"]
+    h.close()
+    assert np.isfinite(K).all() and np.isfinite(H).all() and np.isfinite(g["K"]).all()
+    assert (svd_rows > 0.9 * len(P)) == ("1to20" in tag)
+    rows = np.random.default_rng(3).choice(len(P), 1200, replace=False)
+    diag = [_design_diagnostics(P, i, g["idx"][i]) for i in rows]
+    rel = np.array([d[0] for d in diag])
+    dot = np.array([d[1] for d in diag])
+    rc = np.finfo(np.float64).eps * k
+    band = ((rel > rc / 100) & (rel < rc * 100)).any(1)
+    kept_min = np.where(rel > rc, rel, np.inf).min(1)
+    noisy = ~band & (kept_min < 1e-6)
+    stable = ~band & ~noisy
+    unsigned = ~(np.abs(dot) > 1e-9)                              # zero, noise or NaN
+    Kg, Hg, Kr, Hr = K[rows], H[rows], g["K"][rows], g["H"][rows]
+    Hg = np.where(unsigned, np.abs(Hg), Hg)
+    Hr = np.where(unsigned, np.abs(Hr), Hr)
+    fK, fH = 1e-3, 1e-3                                           # absolute floors: the surfaces' curvatures are O(0.1 .. 1)
+    for cls, tol in ((stable, 1e-5), (noisy, 1e-3)):
+        okK = oracle.curvature_tolerance_ok(Kg[cls], Kr[cls], fK, tol)
+        okH = oracle.curvature_tolerance_ok(Hg[cls], Hr[cls], fH, tol)
+        assert okK.all() and okH.all(), (tag, tol, int((~okK).sum()), int((~okH).sum()))
+    print(f"{tag}: svd rows {svd_rows}, sampled stable {stable.sum()} noisy {noisy.sum()} band {band.sum()} unsigned {unsigned.sum()}")
+
+
 # ------------------------------------------------------- seeded vs the oracle
 @pytest.mark.parametrize("k", [6, 30, 50, 63, 64, 80, 100, 127])
 def test_knn_k_sweep(gpu, k):
@@ -206,6 +299,13 @@ def test_pipeline_vs_oracle_100k(gpu, shape, k):
     ref = oracle.pipeline_batched(pts, k)
     assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
     assert_curvature(K, H, ref["K"], ref["H"])
+    # the vectorised flavour solves normal equations like the kernel's main path: a shared blind spot.  Rows of the
+    # reference-faithful loop (np.cov / svd / lstsq per point, bit-identical to the reference on the goldens) as well.
+    rows = np.random.default_rng(9).choice(len(pts), 1500, replace=False)
+    loop = oracle.pipeline_loop(pts, k, rows)
+    assert np.array_equal(pc.neighbor_indices[rows], loop["idx"])
+    assert_curvature(K[rows], H[rows], loop["K"], loop["H"])
+    assert pc.last_timings["fit_svd_rows"] == 0                 # nothing ill-conditioned on these shapes
     if shape == "sphere":     # closed form K = H = 1 up to the estimator's own O(h^2) bias
         assert np.abs(K - 1).max() < 2e-3 and np.abs(H - 1).max() < 2e-3
 
@@ -460,6 +560,37 @@ def test_host_supplied_indices_and_validation(gpu, golden):
     bad[7, 3] = len(g["points"])                             # IndexError in the reference (pct:640)
     with pytest.raises(ValueError, match="out of range"):
         h.fit_indices(bad)
+    h.close()
+
+
+def test_long_rows_and_the_kernels_own_index_guard(gpu, monkeypatch):
+    """pct_fit_indices takes any k the reference's fit would (rows longer than the LDS staging area are walked in
+    global memory), and a table entry outside the cloud -- host validation switched off -- is never dereferenced."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(3000, seed=8)
+    idx, _ = oracle.knn(pts, 300)
+    rows = np.arange(0, 3000, 7)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.fit_indices(idx[rows], query=rows)
+    co, K, H, _ = h.get_fit(0, len(rows))
+    _, rK, rH, _ = oracle.curvature_batched(pts, idx[rows], rows)
+    assert_curvature(K, H, rK, rH)
+    short = idx[rows][:, :40].copy()
+    h.fit_indices(short, query=rows)
+    good = h.get_fit(0, len(rows))
+    short[5, 7] = 2_000_000_000
+    short[9, 0] = -3
+    with pytest.raises(ValueError):
+        h.fit_indices(short, query=rows)                       # the reference: IndexError at pct:640
+    monkeypatch.setenv("PCT_TRUST_ROWS", "1")
+    h.fit_indices(short, query=rows)
+    got = h.get_fit(0, len(rows))
+    monkeypatch.delenv("PCT_TRUST_ROWS")
+    bad = np.zeros(len(rows), bool)
+    bad[[5, 9]] = True
+    for a, b in zip(got, good):
+        assert np.isnan(a[bad]).all() and np.array_equal(a[~bad], b[~bad])
     h.close()
 
 
@@ -945,9 +1076,12 @@ def test_float64_diagnostics_fit(gpu):
         assert np.allclose(got, sol, rtol=1e-7, atol=1e-9 * np.abs(sol).max())
     with pytest.raises(ValueError):
         h.fit_indices_f64(idx[:, :3] * 0 + 40_000)                           # out-of-range index
-    # eps rows with fewer than 6 neighbours: NaN, as the float32 path
-    c, K, H = h.fit_indices_f64(idx[:2], count=np.array([3, 50], np.int32), query=rows[:2])
-    assert np.isnan(c[0]).all() and np.isnan(K[0]) and np.isfinite(c[1]).all()
+    # rows with 2..5 valid neighbours: lstsq's minimum-norm answer (pct:359), as the float32 path; fewer: NaN
+    # (five, not three: three points lie IN their plane, the orientation test's dot product is rounding noise)
+    c, K, H = h.fit_indices_f64(idx[:3], count=np.array([5, 50, 1], np.int32), query=rows[:3])
+    few = oracle.quadric_fit(oracle.plane_align(pts[idx[0, :5]] - pts[rows[0]]))
+    assert np.allclose(c[0], few, rtol=1e-5, atol=1e-6 * np.abs(few).max()) and np.isfinite(c[1]).all()
+    assert np.isnan(c[2]).all() and np.isnan(K[2])
     h.close()
 
 
