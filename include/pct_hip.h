@@ -146,6 +146,17 @@ int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end,
 int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t rows,
                                      float* K, float* H, float* H2);
 
+/* The two per-neighbourhood staticmethods of the class on their own, batched (batch neighbourhoods of m points):
+ * get_best_fit_plane_and_rotate (pct:270-321): nbrs (batch, m, 3) float32 (is_f64 == 0) or float64 ->
+ * rotated (batch, m, 3) float64: np.cov in float64 (ddof 1), normal = direction of least variance, flipped by
+ * points[-1] - points[0] (subtracted in the input's dtype), Rodrigues rotation of the normal onto +z, R p per point.
+ * PCT_ERR_NONFINITE for NaN/Inf in the input (pct:273) -- the caller checks the output (pct:318).  m >= 2. */
+int pct_plane_rotate(pct_ctx* ctx, const void* nbrs, int32_t is_f64, int64_t batch, int32_t m, double* rotated);
+/* fit_quadratic_surface (pct:331-360): pts (batch, m, 3) float32 (the cast of pct:350 is the caller's) ->
+ * coefs (batch, 6) float32: numpy.linalg.lstsq(rcond=None) of the float32 design rows [a^2, b^2, ab, a, b, 1] --
+ * float64 SVD-based solve, singular values below eps max(m, 6) sigma_1 cut off, minimum-norm solution. */
+int pct_fit_quadric(pct_ctx* ctx, const float* pts, int64_t batch, int32_t m, float* coefs);
+
 /* self.kdtree.query(x, k[, distance_upper_bound=eps]) (the reference's tree object, pointCloudToolbox.py:74; called
  * with arbitrary points at pct:625, 759, 844): the k nearest CLOUD points of each of m caller-supplied float64 query
  * points -- nothing is dropped (a query that coincides with a cloud point gets that point first, distance 0).
@@ -197,6 +208,8 @@ int pct_write_ply_ascii(const char* path, const float* xyz, const float* gaussia
 
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
+/* sizeof(pct_timings) as the library was built: a binding checks its own struct against it at load time. */
+int pct_timings_size(void);
 /* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */
 int pct_device_alloc(pct_ctx* ctx, int64_t bytes, void** dev_ptr);
 int pct_device_free(pct_ctx* ctx, void* dev_ptr);

@@ -74,6 +74,8 @@ SIGNATURES = {
     "pct_curvatures_from_coefficients": (C.c_int, [_p, _f32p, C.c_int64, _f32p, _f32p, _f32p]),
     "pct_neighbor_study_curvatures": (C.c_int, [_p, _i64p, C.c_int64, C.c_int32, C.c_int32, _f32p]),
     "pct_fit_indices_f64": (C.c_int, [_p, _i32p, _i32p, _i64p, C.c_int64, C.c_int32, _f64p, _f64p, _f64p]),
+    "pct_plane_rotate": (C.c_int, [_p, _p, C.c_int32, C.c_int64, C.c_int32, _f64p]),
+    "pct_fit_quadric": (C.c_int, [_p, _f32p, C.c_int64, C.c_int32, _f32p]),
     "pct_query_points": (C.c_int, [_p, _f64p, C.c_int64, C.c_int32, C.c_double, _i32p, _f64p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
     "pct_voxel_downsample": (C.c_int, [_p, _f64p, C.c_int64, C.c_double, _i64p, _i64p]),
@@ -83,6 +85,7 @@ SIGNATURES = {
     "pct_format_float": (C.c_int, [C.c_double, C.c_char_p]),
     "pct_write_ply_ascii": (C.c_int, [C.c_char_p, _f32p, _f32p, _f32p, C.c_int64]),
     "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
+    "pct_timings_size": (C.c_int, []),
     "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
     "pct_device_free": (C.c_int, [_p, _p]),
     "pct_device_upload": (C.c_int, [_p, _p, _p, C.c_int64]),
@@ -115,6 +118,9 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the ABI and this table diverge
         fn.restype = res
         fn.argtypes = args
+    if lib.pct_timings_size() != C.sizeof(Timings):
+        raise HipExtensionError(f"{LIB_PATH}: pct_timings is {lib.pct_timings_size()} bytes, this binding expects "
+                                f"{C.sizeof(Timings)} (library and package out of step: rebuild)")
     _lib = lib
     return lib
 
@@ -309,6 +315,26 @@ class Handle:
         self._check(self._lib.pct_curvatures_from_coefficients(self._h, _ptr(c, _f32p), len(c), _ptr(k, _f32p),
                                                                _ptr(h, _f32p), _ptr(h2, _f32p)))
         return k, h, h2
+
+    def plane_rotate(self, nbrs):
+        """get_best_fit_plane_and_rotate for a block of neighbourhoods: (batch, m, 3) float32 / float64 -> float64."""
+        a = np.asarray(nbrs)
+        a = np.ascontiguousarray(a, dtype=np.float64 if a.dtype == np.float64 else np.float32)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("neighbourhoods must have shape (batch, m, 3)")
+        out = np.empty(a.shape, np.float64)
+        self._check(self._lib.pct_plane_rotate(self._h, a.ctypes.data_as(_p), int(a.dtype == np.float64), a.shape[0], a.shape[1],
+                                               _ptr(out, _f64p)))
+        return out
+
+    def fit_quadric(self, pts):
+        """fit_quadratic_surface for a block of rotated neighbourhoods: (batch, m, 3) float32 -> (batch, 6) float32."""
+        a = np.ascontiguousarray(pts, dtype=np.float32)
+        if a.ndim != 3 or a.shape[2] != 3:
+            raise ValueError("Input points must have shape (batch, N, 3)")
+        out = np.empty((a.shape[0], 6), np.float32)
+        self._check(self._lib.pct_fit_quadric(self._h, _ptr(a, _f32p), a.shape[0], a.shape[1], _ptr(out, _f32p)))
+        return out
 
     def neighbor_study_curvatures(self, sample_rows, n_lo, n_hi):
         rows = np.ascontiguousarray(sample_rows, dtype=np.int64)

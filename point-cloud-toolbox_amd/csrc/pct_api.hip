@@ -519,6 +519,36 @@ int pct_curvatures_from_coefficients(pct_ctx* ctx, const float* coefs, int64_t r
     return PCT_OK;
 }
 
+int pct_plane_rotate(pct_ctx* ctx, const void* nbrs, int32_t is_f64, int64_t batch, int32_t m, double* rotated) {
+    PCT_TRY(begin_call(ctx));
+    if (!nbrs || !rotated || batch <= 0 || m < 2 || (double)batch * m > 2.0e9) return pct_fail(ctx, PCT_ERR_INVALID, "bad neighbourhood block");
+    const size_t count = (size_t)batch * m * 3, esz = is_f64 ? sizeof(double) : sizeof(float);
+    if (is_f64) { const double* p = (const double*)nbrs; for (size_t i = 0; i < count; ++i) if (!isfinite(p[i])) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points"); }
+    else { const float* p = (const float*)nbrs; for (size_t i = 0; i < count; ++i) if (!isfinite(p[i])) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points"); }
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, count * esz));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, count * sizeof(double)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, nbrs, count * esz, hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_launch_plane_rotate(ctx, ctx->stage_a.p, is_f64 != 0, batch, m, (double*)ctx->stage_b.p));
+    PCT_HIP(ctx, hipMemcpyAsync(rotated, ctx->stage_b.p, count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
+int pct_fit_quadric(pct_ctx* ctx, const float* pts, int64_t batch, int32_t m, float* coefs) {
+    PCT_TRY(begin_call(ctx));
+    if (!pts || !coefs || batch <= 0 || m < 1 || (double)batch * m > 2.0e9) return pct_fail(ctx, PCT_ERR_INVALID, "bad point block");
+    const size_t count = (size_t)batch * m * 3;
+    for (size_t i = 0; i < count; ++i)
+        if (!isfinite(pts[i])) return pct_fail(ctx, PCT_ERR_NONFINITE, "Input contains non-finite values.");
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, count * sizeof(float)));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)batch * 6 * sizeof(float)));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, pts, count * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_launch_quadric_rows(ctx, (const float*)ctx->stage_a.p, batch, m, (float*)ctx->stage_b.p));
+    PCT_HIP(ctx, hipMemcpyAsync(coefs, ctx->stage_b.p, (size_t)batch * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PCT_OK;
+}
+
 int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int64_t n_samples, int32_t n_lo, int32_t n_hi,
                                    float* K_out) {
     PCT_TRY(begin_call(ctx));
@@ -628,6 +658,8 @@ int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {
     ctx->fit_valid = false;
     return PCT_OK;
 }
+
+int pct_timings_size(void) { return (int)sizeof(pct_timings); }
 
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out) {
     if (!ctx || !out) return PCT_ERR_INVALID;

@@ -429,78 +429,49 @@ __global__ __launch_bounds__(256) void k_curv(const float* __restrict__ coefs, i
 //   3. c = V Sigma^+ U^T y over the singular values above the cut-off.
 // One thread per listed row; the list length is read on the device (no host round trip), the grid is fixed.
 // ---------------------------------------------------------------------------
-template <bool F64, bool OUT64>
-__global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict__ list, const int* __restrict__ list_count,
-                                                long long* __restrict__ host_count) {
-    const int total = *list_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = total;           // pinned host word: read at the caller's next synchronisation
-    const float nanf_ = __int_as_float(0x7fc00000);
-    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 64) {
-        const int64_t row = list[it];
-        const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
-        const float4 qp = a.pts[qid];
-        const int64_t out = a.out_by_row ? row : (int64_t)__float_as_int(qp.w) - a.out_base;
-        double qx = qp.x, qy = qp.y, qz = qp.z;
-        if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
-        const int m = a.cnt ? a.cnt[row] : a.k;
-        const int* my = a.table + row * a.pitch;
+// Streaming least squares on the reference's design rows [a^2, b^2, ab, a, b, 1] (pct:358), gelsd semantics.
+struct Lstsq6 {
+    double A[6][6];        // A[c][r]: column c of the triangular factor (rows r <= c in use), after solve(): R V
+    double y[6];           // Q^T z
 
-        // ---- pass 1: moments -> tangent-plane rotation (as k_fit) ----------------------------------------------
-        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
-        double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
-        for (int j = 0; j < m; ++j) {
-            double x, y, z;
-            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
-            if (j == 0) { fx = x; fy = y; fz = z; }
-            lx = x; ly = y; lz = z;
-            sx += x; sy += y; sz += z;
-            sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
-            syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
-        }
-        double rot[9];
-        plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
-
-        // ---- pass 2: Givens QR of the design rows, row by row -------------------------------------------------
-        double A[6][6];        // A[c][r]: column c of the triangular factor (rows r <= c in use), later R V
-        double y[6];
+    __device__ __forceinline__ void init() {
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             y[c] = 0;
 #pragma unroll
             for (int r = 0; r < 6; ++r) A[c][r] = 0;
         }
-#pragma unroll 1
-        for (int j = 0; j < m; ++j) {
-            double px, py, pz;
-            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, px, py, pz);
-            const float pa = (float)((rot[0] * px + rot[1] * py) + rot[2] * pz);
-            const float pb = (float)((rot[3] * px + rot[4] * py) + rot[5] * pz);
-            const float pc = (float)((rot[6] * px + rot[7] * py) + rot[8] * pz);
-            double x[6] = {(double)(pa * pa), (double)(pb * pb), (double)(pa * pb), (double)pa, (double)pb, 1.0};   // pct:358
-            double zi = (double)pc;
+    }
+
+    // one neighbour: its float32 coordinates in the rotated frame; the row is annihilated into R by six Givens rotations
+    __device__ __forceinline__ void add(float pa, float pb, float pc) {
+        double x[6] = {(double)(pa * pa), (double)(pb * pb), (double)(pa * pb), (double)pa, (double)pb, 1.0};   // pct:358
+        double zi = (double)pc;
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const double xr = x[r];
-                if (xr != 0.0) {
-                    const double rr = A[r][r];
-                    const double h = sqrt(rr * rr + xr * xr);
-                    const double inv = 1.0 / h;
-                    const double c = rr * inv, sn = xr * inv;
-                    A[r][r] = h;
+        for (int r = 0; r < 6; ++r) {
+            const double xr = x[r];
+            if (xr != 0.0) {
+                const double rr = A[r][r];
+                const double h = sqrt(rr * rr + xr * xr);
+                const double inv = 1.0 / h;
+                const double c = rr * inv, sn = xr * inv;
+                A[r][r] = h;
 #pragma unroll
-                    for (int c2 = r + 1; c2 < 6; ++c2) {
-                        const double t = A[c2][r];
-                        A[c2][r] = c * t + sn * x[c2];
-                        x[c2] = c * x[c2] - sn * t;
-                    }
-                    const double t = y[r];
-                    y[r] = c * t + sn * zi;
-                    zi = c * zi - sn * t;
+                for (int c2 = r + 1; c2 < 6; ++c2) {
+                    const double t = A[c2][r];
+                    A[c2][r] = c * t + sn * x[c2];
+                    x[c2] = c * x[c2] - sn * t;
                 }
+                const double t = y[r];
+                y[r] = c * t + sn * zi;
+                zi = c * zi - sn * t;
             }
         }
+    }
 
-        // ---- one-sided Jacobi: rotate the columns of A (and of V) until they are mutually orthogonal ------------
+    // one-sided Jacobi on R (R V = U Sigma), then c = V Sigma^+ U^T y over the singular values above
+    // eps * max(m, 6) * sigma_1 (numpy.linalg.lstsq(rcond=None) on float32 input computes in float64: eps = 2^-52)
+    __device__ __forceinline__ void solve(int m, double (&sol)[6]) {
         double V[6][6];        // V[c][r]: column c
 #pragma unroll
         for (int c = 0; c < 6; ++c)
@@ -539,7 +510,6 @@ __global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict
             }
             if (!__any(rotated)) break;
         }
-        // ---- c = V Sigma^+ U^T y, U_c = A_c / sigma_c; cut-off as gelsd (rcond = eps max(m, 6)) ----------------
         double sig2[6], smax2 = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -551,7 +521,8 @@ __global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict
         }
         const double rcond = 2.220446049250313e-16 * (double)(m > 6 ? m : 6);
         const double cut = rcond * sqrt(smax2);
-        double sol[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 6; ++r) sol[r] = 0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             if (sqrt(sig2[c]) > cut) {
@@ -563,6 +534,52 @@ __global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict
                 for (int r = 0; r < 6; ++r) sol[r] = fma(V[c][r], w, sol[r]);
             }
         }
+    }
+};
+
+template <bool F64, bool OUT64>
+__global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict__ list, const int* __restrict__ list_count,
+                                                long long* __restrict__ host_count) {
+    const int total = *list_count;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = total;           // pinned host word: read at the caller's next synchronisation
+    const float nanf_ = __int_as_float(0x7fc00000);
+    for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 64) {
+        const int64_t row = list[it];
+        const int64_t qid = a.row_query32 ? (int64_t)a.row_query32[row] : a.row_query ? a.row_query[row] : row + a.row_offset;
+        const float4 qp = a.pts[qid];
+        const int64_t out = a.out_by_row ? row : (int64_t)__float_as_int(qp.w) - a.out_base;
+        double qx = qp.x, qy = qp.y, qz = qp.z;
+        if (F64) { const double4 qd = a.ptsd[qid]; qx = qd.x; qy = qd.y; qz = qd.z; }
+        const int m = a.cnt ? a.cnt[row] : a.k;
+        const int* my = a.table + row * a.pitch;
+
+        // ---- pass 1: moments -> tangent-plane rotation (as k_fit) ----------------------------------------------
+        double sx = 0, sy = 0, sz = 0, sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+        double fx = 0, fy = 0, fz = 0, lx = 0, ly = 0, lz = 0;
+        for (int j = 0; j < m; ++j) {
+            double x, y, z;
+            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, x, y, z);
+            if (j == 0) { fx = x; fy = y; fz = z; }
+            lx = x; ly = y; lz = z;
+            sx += x; sy += y; sz += z;
+            sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
+            syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
+        }
+        double rot[9];
+        plane_rotation<F64>(m, sx, sy, sz, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
+
+        // ---- pass 2: the design rows, one by one ---------------------------------------------------------------
+        Lstsq6 ls;
+        ls.init();
+#pragma unroll 1
+        for (int j = 0; j < m; ++j) {
+            double px, py, pz;
+            load_centred<F64>(a, (int)min((unsigned)my[j], a.n_pts - 1u), qx, qy, qz, qp.x, qp.y, qp.z, px, py, pz);
+            ls.add((float)((rot[0] * px + rot[1] * py) + rot[2] * pz), (float)((rot[3] * px + rot[4] * py) + rot[5] * pz),
+                   (float)((rot[6] * px + rot[7] * py) + rot[8] * pz));
+        }
+        double sol[6];
+        ls.solve(m, sol);
         if (m < 2) {
 #pragma unroll
             for (int r = 0; r < 6; ++r) sol[r] = (double)nanf_;
@@ -585,6 +602,62 @@ __global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict
             a.H2[out] = Kh * Kh;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// The two per-neighbourhood staticmethods of the class surface on their own ("methods of rows A1-A10"),
+// batched: one thread per neighbourhood of m points.
+//   k_plane_rotate   get_best_fit_plane_and_rotate (pct:270-321): np.cov (mean first, then centred products, float64,
+//                    ddof = 1) -> normal -> flip by points[-1] - points[0] (native dtype) -> Rodrigues -> R p, float64
+//   k_quadric_rows   fit_quadratic_surface (pct:331-360): float32 points -> lstsq (gelsd semantics) -> float32 (6,)
+// ---------------------------------------------------------------------------
+template <bool F64>
+__global__ __launch_bounds__(64) void k_plane_rotate(const void* __restrict__ nbrs, int64_t batch, int m, double* __restrict__ out) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    const auto at = [&](int j, double& x, double& y, double& z) {
+        if (F64) { const double* p = (const double*)nbrs + (b * m + j) * 3; x = p[0]; y = p[1]; z = p[2]; }
+        else { const float* p = (const float*)nbrs + (b * m + j) * 3; x = (double)p[0]; y = (double)p[1]; z = (double)p[2]; }
+    };
+    double mx = 0, my = 0, mz = 0;
+    for (int j = 0; j < m; ++j) { double x, y, z; at(j, x, y, z); mx += x; my += y; mz += z; }
+    mx /= (double)m; my /= (double)m; mz /= (double)m;
+    double sxx = 0, sxy = 0, sxz = 0, syy = 0, syz = 0, szz = 0;
+    for (int j = 0; j < m; ++j) {
+        double x, y, z;
+        at(j, x, y, z);
+        x -= mx; y -= my; z -= mz;
+        sxx = fma(x, x, sxx); sxy = fma(x, y, sxy); sxz = fma(x, z, sxz);
+        syy = fma(y, y, syy); syz = fma(y, z, syz); szz = fma(z, z, szz);
+    }
+    double fx, fy, fz, lx, ly, lz;
+    at(0, fx, fy, fz);
+    at(m - 1, lx, ly, lz);
+    double rot[9];
+    plane_rotation<F64>(m, 0.0, 0.0, 0.0, sxx, sxy, sxz, syy, syz, szz, fx, fy, fz, lx, ly, lz, rot);
+    for (int j = 0; j < m; ++j) {
+        double x, y, z;
+        at(j, x, y, z);
+        double* o = out + (b * m + j) * 3;
+        o[0] = (rot[0] * x + rot[1] * y) + rot[2] * z;
+        o[1] = (rot[3] * x + rot[4] * y) + rot[5] * z;
+        o[2] = (rot[6] * x + rot[7] * y) + rot[8] * z;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_quadric_rows(const float* __restrict__ pts, int64_t batch, int m, float* __restrict__ coefs) {
+    const int64_t b = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    Lstsq6 ls;
+    ls.init();
+#pragma unroll 1
+    for (int j = 0; j < m; ++j) {
+        const float* p = pts + (b * m + j) * 3;
+        ls.add(p[0], p[1], p[2]);
+    }
+    double sol[6];
+    ls.solve(m, sol);
+    for (int j = 0; j < 6; ++j) coefs[b * 6 + j] = (float)sol[j];
 }
 
 // explicit_quadratic_neighbor_study (pct:756-761): row (s, n) = the sample point itself followed by its n nearest
@@ -773,6 +846,22 @@ int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, floa
     const int blocks = (int)((rows + 255) / 256);
     if (blocks <= 0) return PCT_OK;
     hipLaunchKernelGGL(k_curv, dim3(blocks), dim3(256), 0, ctx->stream, d_coefs, rows, d_K, d_H, d_H2);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_launch_plane_rotate(pct_ctx* ctx, const void* d_nbrs, bool f64, int64_t batch, int32_t m, double* d_out) {
+    const unsigned blocks = (unsigned)((batch + 63) / 64);
+    if (f64)
+        hipLaunchKernelGGL(k_plane_rotate<true>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
+    else
+        hipLaunchKernelGGL(k_plane_rotate<false>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_launch_quadric_rows(pct_ctx* ctx, const float* d_pts, int64_t batch, int32_t m, float* d_coefs) {
+    hipLaunchKernelGGL(k_quadric_rows, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, d_pts, batch, m, d_coefs);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

@@ -195,6 +195,8 @@ int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_pos, int64_t n_samp
                            int pitch, int* d_cnt, int64_t* d_row_query);
 int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2);
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2);
+int pct_launch_plane_rotate(pct_ctx* ctx, const void* d_nbrs, bool f64, int64_t batch, int32_t m, double* d_out);
+int pct_launch_quadric_rows(pct_ctx* ctx, const float* d_pts, int64_t batch, int32_t m, float* d_coefs);
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails);
 int pct_ensure_plain_records(pct_ctx* ctx);
 int pct_launch_fit_rows_f64(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt, const int64_t* d_query, int64_t rows,

@@ -18,7 +18,9 @@ Deliberate, documented differences (none changes a value):
 """
 from __future__ import annotations
 
+import atexit
 import gc
+import threading
 
 import numpy as np
 
@@ -329,15 +331,64 @@ class PointCloud:
         return K, H
 
     # --------------------------------------------------------- staticmethods
+    # The reference calls these once per point in a Python loop (pct:644-647, 668): one device context serves all
+    # calls of the process (created on first use, released at exit), under a lock -- a handle has ONE stream.
+    @staticmethod
+    def get_best_fit_plane_and_rotate(points):
+        """pct:270-321 for one neighbourhood: (k, 3) -> (k, 3) float64 with the best-fit normal on +z."""
+        pts = np.asarray(points)
+        if not np.all(np.isfinite(pts)):
+            raise ValueError("Non-finite values in input points")                      # pct:273-274
+        if pts.ndim != 2 or pts.shape[1] != 3 or pts.shape[0] < 2:
+            return _reference_small_case(pts)
+        with _static_lock:
+            rotated = _static_handle().plane_rotate(pts[None])[0]
+        if not np.all(np.isfinite(rotated)):
+            raise ValueError("Non-finite values after rotation")                       # pct:318-319
+        return rotated
+
+    @staticmethod
+    def fit_quadratic_surface(points):
+        """pct:331-360 for one neighbourhood: (N, 3) [a, b, z] -> float32 (6,) [A, B, C, D, E, F]."""
+        points = np.array(points, dtype=np.float32)                                    # pct:350
+        if points.ndim != 2 or points.shape[1] != 3:
+            raise ValueError("Input points must have shape (N, 3)")                    # pct:351-352
+        if not np.all(np.isfinite(points)):
+            raise ValueError("Input contains non-finite values.")                      # pct:356-357
+        if points.shape[0] == 0:
+            raise np.linalg.LinAlgError("0-dimensional array given")                   # what lstsq says to an empty system
+        with _static_lock:
+            return _static_handle().fit_quadric(points[None])[0]
+
     @staticmethod
     def calculate_explicit_quadratic_curvatures(coefficients):
         """pct:398-431 for one coefficient vector (device evaluation)."""
-        h = _capi.Handle(0)
-        try:
-            c = np.asarray(coefficients, dtype=np.float32).reshape(1, 6)
-            K, H, H2 = h.curvatures_from_coefficients(c)
-        finally:
-            h.close()
+        c = np.asarray(coefficients, dtype=np.float32).reshape(1, 6)
+        with _static_lock:
+            K, H, H2 = _static_handle().curvatures_from_coefficients(c)
         disc = max(H[0] ** 2 - K[0], 0)                      # pct:425
         root = np.sqrt(disc)
         return K[0], H[0], H[0] + root, H[0] - root, H2[0]
+
+
+_static_lock = threading.Lock()
+_static = {"handle": None}
+
+
+def _static_handle():
+    if _static["handle"] is None:
+        _static["handle"] = _capi.Handle(0)                 # raises without library / GPU: no CPU fallback
+        atexit.register(_close_static_handle)
+    return _static["handle"]
+
+
+def _close_static_handle():
+    h, _static["handle"] = _static["handle"], None
+    if h is not None:
+        h.close()
+
+
+def _reference_small_case(pts):
+    # a single point or a malformed block: np.cov of pct:277 has nothing to average -- NaN normal -> the reference's
+    # second finite check fires
+    raise ValueError("Non-finite values after rotation")

@@ -155,6 +155,43 @@ def test_degenerate_unit_neighbourhoods(gpu, golden):
     h.close()
 
 
+def test_staticmethods_of_the_class(gpu, golden):
+    """PointCloud.get_best_fit_plane_and_rotate / fit_quadratic_surface (pct:270-321, 331-360) as callable
+    staticmethods, against the blocks the reference's own staticmethods returned (G6 / G6b `_rot`, `_coefs`)."""
+    PC = gpu["PointCloud"]
+    free_normal = {"line_axis", "line_axis_f32", "line_oblique", "line_noise1e6", "planar_curve", "aniso_lattice_1to20"}
+    for name in ("g6_unit_cases.npz", "g6b_degenerate_unit_cases.npz"):
+        g = golden(name)
+        for n in sorted(k[:-3] for k in g if k.endswith("_in")):
+            nb, ref_rot, ref_c = g[n + "_in"], g[n + "_rot"], g[n + "_coefs"]
+            rot = PC.get_best_fit_plane_and_rotate(nb)
+            assert rot.shape == nb.shape and rot.dtype == np.float64, n
+            if n not in free_normal:       # (collinear / planar input: the normal is LAPACK's pick in a null space)
+                assert np.allclose(rot, ref_rot, rtol=0, atol=1e-13 * np.abs(nb).max()), n
+            # lengths and the best-fit normal's alignment survive whatever the pick
+            assert np.allclose(np.linalg.norm(rot, axis=1), np.linalg.norm(nb.astype(np.float64), axis=1), rtol=1e-12, atol=1e-18), n
+            cf = PC.fit_quadratic_surface(ref_rot)                        # the reference's own rotated block in
+            assert cf.shape == (6,) and cf.dtype == np.float32, n
+            if n not in ("line_noise1e6", "line_oblique"):
+                scale = max(1.0, float(np.abs(ref_c[:3]).max()))
+                assert np.allclose(cf, ref_c, rtol=1e-5, atol=2e-6 * scale), (n, cf, ref_c)
+            out = PC.calculate_explicit_quadratic_curvatures(ref_c)
+            assert np.allclose(np.array(out, np.float32), g[n + "_curv"], rtol=1e-6, atol=1e-30), n
+    with pytest.raises(ValueError, match="Non-finite values in input points"):
+        PC.get_best_fit_plane_and_rotate(np.array([[0, 0, 0], [1, np.nan, 0], [0, 1, 0.0]]))
+    with pytest.raises(ValueError, match="Input points must have shape"):
+        PC.fit_quadratic_surface(np.zeros((5, 2)))
+    with pytest.raises(ValueError, match="Input contains non-finite values"):
+        PC.fit_quadratic_surface(np.array([[0, 0, 0], [1, np.inf, 0], [0, 1, 0.0]]))
+    # the loop the reference runs (pct:638-647) reproduces the fused result row by row
+    g2 = golden("g2_torus4k_k50.npz")
+    P = g2["points"]
+    for i in (0, 17, 3999):
+        rot = PC.get_best_fit_plane_and_rotate(P[g2["idx"][i]] - P[i])
+        cf = PC.fit_quadratic_surface(rot)
+        assert np.allclose(cf, g2["coefs"][i], rtol=1e-5, atol=1e-6 * np.abs(g2["coefs"][i]).max())
+
+
 @pytest.mark.parametrize("tag", ["plane_1to20", "cyl_1to20", "wavy_1to20", "wavy_1to4", "wavy_1to4_jitter"])
 def test_scan_line_clouds_against_the_reference(gpu, golden, tag):
     """G10: clouds sampled densely along scan lines and sparsely across (0.005 x 0.1 / 0.02, k = 30: every
