@@ -184,14 +184,19 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
                       double* out3);
 
 /* ---- scan preparation (next row N4) ---------------------------------------- */
-/* Voxel-grid down-sampling of convert_asc_to_ply.py:20-51: voxel = floor(coordinate / voxel_size) in float64, the
+/* Voxel-grid down-sampling of convert_asc_to_ply.py:20-51: voxel = floor(coordinate / voxel_size) evaluated in the
+ * coordinates' own dtype as NumPy does (the _f32 form divides by (float)voxel_size in float32), the
  * first point of every voxel is kept.  indices (caller-allocated, n entries) receives the kept input indices in
  * increasing order (= the reference's order of first occurrence), *count their number.  Works on any handle, with or
  * without a resident cloud; it borrows the cell list's scratch buffers, so a resident neighbour table is dropped
  * (plant it again before pct_fit / pct_get_neighbors); fit results already computed stay readable. */
 int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count);
-/* PCA surface variation of utils.py:778-829 for the loaded cloud: k_total neighbours including the point itself,
- * out[i] = lambda_min / (lambda_0 + lambda_1 + lambda_2 + 1e-10), (owned rows) float32. */
+int pct_voxel_downsample_f32(pct_ctx* ctx, const float* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count);
+/* PCA surface variation as utils.py:778-829 DOCUMENTS it, for the loaded cloud: k_total neighbours including the point
+ * itself, out[i] = lambda_min / (lambda_0 + lambda_1 + lambda_2 + 1e-10) of their 3 x 3 covariance, (owned rows)
+ * float32.  (As WRITTEN, utils.py:822 builds the k x k Gram matrix, whose smallest eigenvalue is zero: the function
+ * returns LAPACK round-off around 0.  The Python wrapper's default follows the code as written -- zeros -- and offers
+ * this estimator as an option.) */
 int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out);
 
 /* ---- ingest / egress around the path (host code, no device needed) ------- */

@@ -374,8 +374,10 @@ def mesh_energies(vertices, triangles, gaussian_curvature, mean_curvature):
 
 
 # --------------------------------------------------------------------------
-# N4  scan preparation.  Neither function is importable from the reference here (convert_asc_to_ply.py runs its
-# conversion at import time, utils.py needs open3d): restated from the text; parity unpinned by a reference run.
+# N4  scan preparation.  Neither MODULE is importable here (convert_asc_to_ply.py runs its conversion at import time,
+# utils.py needs open3d), but the two function definitions compile on their own: oracle/make_goldens_prep.py runs the
+# reference's own bodies on seeded inputs (tests/golden/g11_prep.npz) and tests/test_prep.py holds these restatements
+# to them -- pinned.
 # --------------------------------------------------------------------------
 def voxel_downsample(coordinates, voxel_size=0.1):
     """/root/reference/convert_asc_to_ply.py:20-51."""

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pct_query_points": (C.c_int, [_p, _f64p, C.c_int64, C.c_int32, C.c_double, _i32p, _f64p]),
     "pct_mesh_energies": (C.c_int, [_p, _f64p, C.c_int64, _i32p, C.c_int64, _p, _p, C.c_int32, _f64p]),
     "pct_voxel_downsample": (C.c_int, [_p, _f64p, C.c_int64, C.c_double, _i64p, _i64p]),
+    "pct_voxel_downsample_f32": (C.c_int, [_p, _f32p, C.c_int64, C.c_double, _i64p, _i64p]),
     "pct_surface_variation": (C.c_int, [_p, C.c_int32, _f32p]),
     "pct_text_shape": (C.c_int, [C.c_char_p, _i64p, _i32p]),
     "pct_text_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, _f64p]),
@@ -358,10 +359,17 @@ class Handle:
         return float(out[0]), float(out[1]), float(out[2])
 
     def voxel_downsample(self, xyz, voxel_size):
-        p = np.ascontiguousarray(xyz, dtype=np.float64).reshape(-1, 3)
+        """Indices of the first point of every voxel.  float32 coordinates are binned in float32, everything else in
+        float64 -- as ``np.floor(coordinates / voxel_size)`` evaluates (convert_asc_to_ply.py:34)."""
+        xyz = np.asarray(xyz)
+        f32 = xyz.dtype == np.float32
+        p = np.ascontiguousarray(xyz, dtype=np.float32 if f32 else np.float64).reshape(-1, 3)
         idx = np.empty(len(p), np.int64)
         cnt = C.c_int64(0)
-        self._check(self._lib.pct_voxel_downsample(self._h, _ptr(p, _f64p), len(p), float(voxel_size), _ptr(idx, _i64p), C.byref(cnt)))
+        if f32:
+            self._check(self._lib.pct_voxel_downsample_f32(self._h, _ptr(p, _f32p), len(p), float(voxel_size), _ptr(idx, _i64p), C.byref(cnt)))
+        else:
+            self._check(self._lib.pct_voxel_downsample(self._h, _ptr(p, _f64p), len(p), float(voxel_size), _ptr(idx, _i64p), C.byref(cnt)))
         return idx[:cnt.value].copy()
 
     def surface_variation(self, k_total):

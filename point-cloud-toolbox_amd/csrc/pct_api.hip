@@ -623,20 +623,31 @@ int pct_mesh_energies(pct_ctx* ctx, const double* vertices, int64_t n_vertices, 
     return PCT_OK;
 }
 
-int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count) {
+static int voxel_downsample(pct_ctx* ctx, const void* xyz, bool f64, int64_t n, double voxel_size, int64_t* indices, int64_t* count) {
     PCT_TRY(begin_call(ctx));
-    if (!xyz || !indices || !count || n <= 0 || n >= 0x7F000000 || !(voxel_size > 0))
+    if (!xyz || !indices || !count || n <= 0 || n >= 0x7F000000 || !(voxel_size > 0) || (!f64 && !((float)voxel_size > 0.f)))
         return pct_fail(ctx, PCT_ERR_INVALID, "bad down-sampling arguments");
-    for (int64_t i = 0; i < 3 * n; ++i)
-        if (!isfinite(xyz[i]) || fabs(xyz[i] / voxel_size) >= 2147483000.0)
+    for (int64_t i = 0; i < 3 * n; ++i) {
+        const double v = f64 ? ((const double*)xyz)[i] : (double)((const float*)xyz)[i];
+        if (!isfinite(v) || fabs(v / voxel_size) >= 2147483000.0)
             return pct_fail(ctx, PCT_ERR_INVALID, "coordinate %lld does not map to an int32 voxel index", (long long)(i / 3));
-    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, (size_t)n * 3 * sizeof(double)));
+    }
+    const size_t bytes = (size_t)n * 3 * (f64 ? sizeof(double) : sizeof(float));
+    PCT_TRY(pct_reserve(ctx, &ctx->stage_a, bytes));
     PCT_TRY(pct_reserve(ctx, &ctx->stage_b, (size_t)n * sizeof(int64_t)));
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, xyz, (size_t)n * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-    PCT_TRY(pct_voxel_downsample_device(ctx, (const double*)ctx->stage_a.p, n, voxel_size, (int64_t*)ctx->stage_b.p, count));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->stage_a.p, xyz, bytes, hipMemcpyHostToDevice, ctx->stream));
+    PCT_TRY(pct_voxel_downsample_device(ctx, ctx->stage_a.p, f64, n, voxel_size, (int64_t*)ctx->stage_b.p, count));
     if (*count > 0) PCT_HIP(ctx, hipMemcpyAsync(indices, ctx->stage_b.p, (size_t)*count * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PCT_OK;
+}
+
+int pct_voxel_downsample(pct_ctx* ctx, const double* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count) {
+    return voxel_downsample(ctx, xyz, true, n, voxel_size, indices, count);
+}
+
+int pct_voxel_downsample_f32(pct_ctx* ctx, const float* xyz, int64_t n, double voxel_size, int64_t* indices, int64_t* count) {
+    return voxel_downsample(ctx, xyz, false, n, voxel_size, indices, count);
 }
 
 int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {

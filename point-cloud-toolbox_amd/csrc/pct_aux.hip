@@ -1,7 +1,7 @@
 // Next row N4 of the scope table: the two scan-preparation steps that share building blocks with the path.
 //
 // 1. Voxel-grid down-sampling, /root/reference/convert_asc_to_ply.py:20-51: voxel = floor(coordinate / voxel_size)
-//    in float64, keep the FIRST point (lowest input index) of every voxel, output in order of first occurrence.
+//    in the coordinates' dtype, keep the FIRST point (lowest input index) of every voxel, output in order of first occurrence.
 //    GPU form: open-addressing hash table on the packed voxel key (64-bit atomicCAS) holding the minimum point index
 //    (atomicMin), then an order-preserving compaction of the representatives.
 // 2. PCA surface variation, /root/reference/utils.py:778-829: k = min(max(5, int(0.025 N)), 100) neighbours INCLUDING
@@ -23,14 +23,17 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long x) {
     return x;
 }
 
-// voxel coordinates as the reference computes them: np.floor(coordinates / voxel_size).astype(np.int32)
-__global__ __launch_bounds__(256) void k_voxel_keys(const double* __restrict__ xyz, int64_t n, double voxel, int* __restrict__ vox,
+// voxel coordinates as the reference computes them: np.floor(coordinates / voxel_size).astype(np.int32) IN THE ARRAY'S
+// DTYPE -- NumPy divides a float32 array by a Python float in float32 (the scalar is rounded to float32 first), and on
+// coordinates that are multiples of the voxel size the quotient's last bit decides the voxel
+template <typename T>
+__global__ __launch_bounds__(256) void k_voxel_keys(const T* __restrict__ xyz, int64_t n, T voxel, int* __restrict__ vox,
                                                     int* __restrict__ red) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     int v[3] = {0, 0, 0};
     if (i < n) {
         for (int a = 0; a < 3; ++a) {
-            v[a] = (int)floor(xyz[3 * i + a] / voxel);
+            v[a] = (int)floor(xyz[3 * i + a] / voxel);          // IEEE division and floor in T
             vox[3 * i + a] = v[a];
         }
     }
@@ -176,13 +179,16 @@ __global__ __launch_bounds__(64) void k_surface_variation(const float4* __restri
 
 }  // namespace
 
-int pct_voxel_downsample_device(pct_ctx* ctx, const double* d_xyz, int64_t n, double voxel, int64_t* d_out, int64_t* count) {
+int pct_voxel_downsample_device(pct_ctx* ctx, const void* d_xyz, bool f64, int64_t n, double voxel, int64_t* d_out, int64_t* count) {
     PCT_TRY(pct_reserve(ctx, &ctx->red, 64));
     int init[8] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0, 0};
     PCT_HIP(ctx, hipMemcpyAsync(ctx->red.p, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * 3 * sizeof(int)));
     const int blocks = (int)((n + 255) / 256);
-    hipLaunchKernelGGL(k_voxel_keys, dim3(blocks), dim3(256), 0, ctx->stream, d_xyz, n, voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
+    if (f64)
+        hipLaunchKernelGGL(k_voxel_keys<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_xyz, n, voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
+    else
+        hipLaunchKernelGGL(k_voxel_keys<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)d_xyz, n, (float)voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
     int mm[8];
     PCT_HIP(ctx, hipMemcpyAsync(mm, ctx->red.p, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -206,5 +206,5 @@ int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t 
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt);
 int pct_launch_mesh_energies(pct_ctx* ctx, const double* d_v, const int* d_tri, int64_t n_tri, const void* d_K, const void* d_H,
                              bool f64, double* d_partial, int nblk, double* d_out);
-int pct_voxel_downsample_device(pct_ctx* ctx, const double* d_xyz, int64_t n, double voxel, int64_t* d_out, int64_t* count);
+int pct_voxel_downsample_device(pct_ctx* ctx, const void* d_xyz, bool f64, int64_t n, double voxel, int64_t* d_out, int64_t* count);
 int pct_launch_surface_variation(pct_ctx* ctx, float* d_out);
