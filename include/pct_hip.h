@@ -211,6 +211,25 @@ int pct_format_float(double x, char* out32);
  * prints them. */
 int pct_write_ply_ascii(const char* path, const float* xyz, const float* gaussian, const float* mean, int64_t n);
 
+/* ---- multi-GPU exchange --------------------------------------------------------------------------
+ * The reference is one process; here the cloud shards by point-index range over up to 8 GPUs, one process per GPU,
+ * and the only exchange is an all-gather of the float32 coordinate shards (12 B / point): RCCL over xGMI, called from
+ * this library (librccl.so is opened at run time; no PyTorch in the process).  Rank 0 creates the unique id and the
+ * host code hands its 128 bytes to every rank (point-cloud-toolbox_amd/dist.py: a TCP socket on MASTER_ADDR). */
+int pct_comm_unique_id(void* id128);
+int pct_comm_init(pct_ctx* ctx, int32_t rank, int32_t world, const void* id128);
+int pct_comm_destroy(pct_ctx* ctx);
+/* Rank r contributes counts[r] floats at dev_send; dev_recv receives all shards back to back in rank order.
+ * Asynchronous: runs on the handle's exchange stream, ordered after the work the compute stream holds at the call. */
+int pct_comm_allgather_f32(pct_ctx* ctx, const void* dev_send, void* dev_recv, const int64_t* counts);
+/* The compute stream waits for the last exchange on the device (the host does not block) ... */
+int pct_comm_wait(pct_ctx* ctx);
+/* ... or the host does. */
+int pct_comm_synchronize(pct_ctx* ctx);
+/* values[0..n) reduced over the ranks in place (op 0 sum, 2 max, 3 min; n <= 8); blocking, also drains this handle's
+ * compute stream first: with n == 0 it is the barrier of the bench's timed region. */
+int pct_comm_allreduce_f64(pct_ctx* ctx, double* values, int32_t n, int32_t op);
+
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
 /* sizeof(pct_timings) as the library was built: a binding checks its own struct against it at load time. */

@@ -85,6 +85,13 @@ SIGNATURES = {
     "pct_text_load": (C.c_int, [C.c_char_p, C.c_int64, C.c_int32, _f64p]),
     "pct_format_float": (C.c_int, [C.c_double, C.c_char_p]),
     "pct_write_ply_ascii": (C.c_int, [C.c_char_p, _f32p, _f32p, _f32p, C.c_int64]),
+    "pct_comm_unique_id": (C.c_int, [_p]),
+    "pct_comm_init": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),
+    "pct_comm_destroy": (C.c_int, [_p]),
+    "pct_comm_allgather_f32": (C.c_int, [_p, _p, _p, _i64p]),
+    "pct_comm_wait": (C.c_int, [_p]),
+    "pct_comm_synchronize": (C.c_int, [_p]),
+    "pct_comm_allreduce_f64": (C.c_int, [_p, _f64p, C.c_int32, C.c_int32]),
     "pct_get_timings": (C.c_int, [_p, C.POINTER(Timings)]),
     "pct_timings_size": (C.c_int, []),
     "pct_device_alloc": (C.c_int, [_p, C.c_int64, C.POINTER(_p)]),
@@ -160,6 +167,14 @@ def device_count():
     n = C.c_int(0)
     load().pct_device_count(C.byref(n))
     return n.value
+
+
+def comm_unique_id():
+    """128 bytes identifying a new RCCL communicator (rank 0 calls this and hands the bytes to every rank)."""
+    buf = C.create_string_buffer(128)
+    if load().pct_comm_unique_id(C.cast(buf, _p)) != PCT_OK:
+        raise HipExtensionError("pct_comm_unique_id failed: librccl.so cannot be opened or refused")
+    return buf.raw
 
 
 def _ptr(a, typ):
@@ -382,6 +397,36 @@ class Handle:
         t = Timings()
         self._lib.pct_get_timings(self._h, C.byref(t))
         return t.as_dict()
+
+    # -- multi-GPU exchange (RCCL behind the C ABI) ---------------------------
+    def comm_init(self, rank, world, unique_id):
+        if len(unique_id) != 128:
+            raise ValueError("the RCCL unique id is 128 bytes")
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(self._lib.pct_comm_init(self._h, int(rank), int(world), C.cast(buf, _p)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._lib.pct_comm_destroy(self._h))
+
+    def comm_allgather(self, dev_send, dev_recv, counts):
+        """Start the all-gather of float32 shards (counts[r] floats from rank r) on the exchange stream."""
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        self._check(self._lib.pct_comm_allgather_f32(self._h, _p(int(dev_send)), _p(int(dev_recv)), _ptr(c, _i64p)))
+
+    def comm_wait(self):
+        self._check(self._lib.pct_comm_wait(self._h))
+
+    def comm_synchronize(self):
+        self._check(self._lib.pct_comm_synchronize(self._h))
+
+    def comm_allreduce(self, values, op="sum"):
+        v = np.ascontiguousarray(np.atleast_1d(values), dtype=np.float64).copy()
+        self._check(self._lib.pct_comm_allreduce_f64(self._h, _ptr(v, _f64p), len(v), {"sum": 0, "max": 2, "min": 3}[op]))
+        return v
+
+    def comm_barrier(self):
+        self._check(self._lib.pct_comm_allreduce_f64(self._h, None, 0, 0))
 
     # -- raw device memory (multi-GPU all-gather target) ---------------------
     def device_alloc(self, nbytes):

@@ -32,8 +32,11 @@ struct pct_buf {
     size_t cap = 0;
 };
 
+struct pct_comm;            // RCCL communicator + exchange stream (pct_comm.hip); null on a single-GPU handle
+
 struct pct_ctx {
     int device = 0;
+    pct_comm* comm = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
     char err[512] = {0};
@@ -136,6 +139,7 @@ struct pct_ctx {
 };
 
 int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...);
+void pct_comm_release(pct_ctx* ctx);
 
 // The fast sweep sorts <= 64 survivors in one register per lane (R = 1) or <= 128 in two (R = 2).  R = 1 would hold
 // k + 1 <= 64, but near that limit the window k+1 <= count <= 64 for the threshold gets narrow and the larger cells

@@ -1,26 +1,31 @@
-"""Point-index-range sharding of the curvature path over up to 8 GPUs.
+"""Point-index-range sharding of the curvature path over up to 8 GPUs -- no PyTorch.
 
-The reference is single-process (nothing to mirror); queries are
-independent, so rank r owns the contiguous index range
-``[r*N/G, (r+1)*N/G)`` of the cloud.  The only exchange is one all-gather of the
-float32 coordinates (12 B/point) so that every GPU holds the whole candidate
-set -- for an unsorted cloud the "halo" of an index range is the whole cloud.
-Outputs need no collective: each rank keeps its K/H rows, neighbour indices are
-global, and results are independent of G.
+The reference is single-process (nothing to mirror); queries are independent, so rank r owns the
+contiguous index range ``[r*N/G, (r+1)*N/G)`` of the cloud.  The only exchange is one all-gather of the float32
+coordinate shards (12 B/point): every GPU receives the whole candidate set and keeps the points near its own range
+(the halo; for an unsorted cloud that is everything).  Outputs need no collective: each rank keeps its K/H rows,
+neighbour indices are global, and results do not depend on G.
 
-``torch.distributed`` is plumbing here (process group, RCCL all-gather when the
-backend is "nccl", gloo on CPU); the compute goes through the C ABI.
+One process per GPU.  Any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT will do
+(``python -m torch.distributed.run`` is used as exactly that and nothing else).  The collective is RCCL over xGMI,
+called from ``libpct_hip.so`` (``pct_comm_*``, include/pct_hip.h) on the handle's exchange stream; rank 0 creates the
+RCCL unique id and :func:`rendezvous_unique_id` hands its 128 bytes to the other ranks over a TCP socket on
+``MASTER_ADDR:MASTER_PORT+1`` (``PCT_RDZV_PORT`` overrides the port).
 
-Load order: PyTorch-ROCm bundles its own ``libamdhip64.so.7``.  A process that
-uses both must ``import torch`` BEFORE the first ``_capi.load()`` so that the
-dynamic loader binds ``libpct_hip.so`` to the HIP runtime that is already
-loaded; two HIP runtimes in one process cannot both open the device.
+CPU tests cover ownership, concatenation and the double-buffered step pattern by injecting an exchange object with
+the same four methods (``tests/test_dist_gloo.py``: torch.distributed's gloo backend, world size 2) and a checker in
+place of the device compute; the rendezvous itself runs there with 2, 4 and 8 processes.
 """
 from __future__ import annotations
 
+import os
+import socket
+import struct
+import time
+
 import numpy as np
 
-__all__ = ["shard_range", "allgather_points", "ShardedCurvature"]
+__all__ = ["shard_range", "shard_sizes", "rendezvous_unique_id", "RcclExchange", "ShardedCurvature", "env_rank"]
 
 
 def shard_range(n_total, rank, world):
@@ -28,95 +33,188 @@ def shard_range(n_total, rank, world):
     return (n_total * rank) // world, (n_total * (rank + 1)) // world
 
 
-def allgather_points(local_pts, n_total, rank, world, device=None):
-    """All-gather the per-rank coordinate shards into the full (N,3) float32 cloud.
+def shard_sizes(n_total, world):
+    return [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
 
-    Returns a torch tensor on ``device`` (RCCL over xGMI for backend "nccl") or
-    on the CPU (gloo).  Shards may differ in size by one row; they are padded to
-    the common maximum for the collective and compacted afterwards.
-    """
-    import torch
-    import torch.distributed as dist
 
-    lo, hi = shard_range(n_total, rank, world)
-    local_pts = np.ascontiguousarray(local_pts, dtype=np.float32)
-    if local_pts.shape != (hi - lo, 3):
-        raise ValueError(f"rank {rank} must hold rows [{lo},{hi}) of the cloud, got {local_pts.shape}")
-    dev = torch.device("cpu") if device is None else torch.device(device)
-    sizes = [shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world)]
-    m = max(sizes)
-    pad = torch.zeros((m, 3), dtype=torch.float32, device=dev)
-    pad[: hi - lo] = torch.from_numpy(local_pts).to(dev)
+def env_rank():
+    """(rank, world, local_rank) as the launcher exported them; a plain ``python`` run is rank 0 of 1."""
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+# ------------------------------------------------------------------ rendezvous
+def _recv_exact(sock, n):
+    buf = bytearray()
+    while len(buf) < n:
+        chunk = sock.recv(n - len(buf))
+        if not chunk:
+            raise ConnectionError("peer closed the rendezvous socket")
+        buf += chunk
+    return bytes(buf)
+
+
+def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180.0):
+    """Rank 0 calls ``make_id()`` (128 bytes) and serves them to the other ``world - 1`` ranks; every rank returns the
+    same bytes.  Each peer announces its rank first, so a stray connection cannot take a slot."""
     if world == 1:
-        return pad[: hi - lo]
-    gathered = torch.empty((world, m, 3), dtype=torch.float32, device=dev)
-    dist.all_gather_into_tensor(gathered.view(world * m, 3), pad)
-    if all(s == m for s in sizes):
-        return gathered.view(world * m, 3)
-    return torch.cat([gathered[r, : sizes[r]] for r in range(world)], 0).contiguous()
+        return make_id()
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    if port is None:
+        port = int(os.environ.get("PCT_RDZV_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 1
+    deadline = time.monotonic() + timeout
+    if rank == 0:
+        payload = make_id()
+        if len(payload) != 128:
+            raise ValueError("the unique id must be 128 bytes")
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("", port))
+        srv.listen(world)
+        served = set()
+        try:
+            while len(served) < world - 1:
+                srv.settimeout(max(0.1, deadline - time.monotonic()))
+                try:
+                    conn, _ = srv.accept()
+                except socket.timeout:
+                    raise TimeoutError(f"rendezvous: {world - 1 - len(served)} of {world - 1} ranks did not call in") from None
+                with conn:
+                    conn.settimeout(10.0)
+                    try:
+                        magic, peer = struct.unpack("!4sI", _recv_exact(conn, 8))
+                    except (ConnectionError, socket.timeout, struct.error):
+                        continue
+                    if magic != b"PCT1" or not (0 < peer < world) or peer in served:
+                        continue
+                    conn.sendall(payload)
+                    served.add(peer)
+        finally:
+            srv.close()
+        return payload
+    last = None
+    while time.monotonic() < deadline:
+        try:
+            with socket.create_connection((addr, port), timeout=5.0) as s:
+                s.sendall(struct.pack("!4sI", b"PCT1", rank))
+                return _recv_exact(s, 128)
+        except (ConnectionRefusedError, ConnectionError, socket.timeout, OSError) as e:     # rank 0 is not listening yet
+            last = e
+            time.sleep(0.05)
+    raise TimeoutError(f"rendezvous: rank {rank} could not reach {addr}:{port}: {last}")
+
+
+# ------------------------------------------------------------------ exchange
+class RcclExchange:
+    """All-gather of device-resident float32 shards through the handle's RCCL communicator (``pct_comm_*``)."""
+
+    def __init__(self, handle, rank, world, addr=None, port=None):
+        from . import _capi
+        self.handle, self.rank, self.world = handle, int(rank), int(world)
+        uid = rendezvous_unique_id(self.rank, self.world, _capi.comm_unique_id, addr, port)
+        handle.comm_init(self.rank, self.world, uid)
+
+    def begin(self, send_ptr, recv_ptr, counts):
+        """Start gathering ``counts[r]`` floats from every rank r into ``recv_ptr`` (exchange stream)."""
+        self.handle.comm_allgather(send_ptr, recv_ptr, counts)
+        return recv_ptr
+
+    def end(self, ticket):
+        """The handle's compute stream waits for the gather on the device; the host does not block."""
+        self.handle.comm_wait()
+        return ticket
+
+    def allreduce(self, values, op="sum"):
+        return self.handle.comm_allreduce(values, op)
+
+    def barrier(self):
+        self.handle.comm_barrier()
+
+    def close(self):
+        self.handle.comm_destroy()
 
 
 class ShardedCurvature:
     """Per-rank driver: all-gather -> neighbour sweep + fit on the owned range.
 
-    ``compute`` is the per-rank kernel entry.  On a GPU rank it is left ``None``
-    and the HIP path is used through ``handle``; CPU tests of the sharding logic
-    inject a checker with the same signature
-    ``compute(full_points(np.ndarray), lo, hi, k, eps) -> (K, H)``.
+    GPU ranks: ``handle`` (a ``_capi.Handle``) and ``exchange`` (an :class:`RcclExchange`); the coordinates live in
+    device buffers the handle allocates (``setup_device``), two gather buffers alternate so that the exchange of cloud
+    i+1 overlaps the kernels of cloud i.  CPU tests inject ``exchange`` (host arrays) and ``compute`` -- a checker with
+    the signature ``compute(full_points, lo, hi, k, eps) -> (K, H)``.
     """
 
-    def __init__(self, n_total, k, rank, world, eps=None, handle=None, device=None, compute=None):
-        self.n_total, self.k, self.rank, self.world, self.eps = int(n_total), int(k), rank, world, eps
-        self.handle, self.device, self.compute = handle, device, compute
+    def __init__(self, n_total, k, rank, world, eps=None, handle=None, exchange=None, compute=None):
+        self.n_total, self.k, self.rank, self.world, self.eps = int(n_total), int(k), int(rank), int(world), eps
+        self.handle, self.exchange, self.compute = handle, exchange, compute
         self.lo, self.hi = shard_range(self.n_total, rank, world)
+        self.counts = np.asarray(shard_sizes(self.n_total, world), dtype=np.int64) * 3       # floats per rank
+        self._send = self._bufs = None
         if handle is None and compute is None:
             raise RuntimeError("ShardedCurvature needs a device handle (HIP path); there is no CPU fallback")
+        if world > 1 and exchange is None:
+            raise RuntimeError("more than one rank needs an exchange (RcclExchange on GPUs)")
 
+    # ---- host arrays: the injected path of the CPU tests -------------------------------------------------------
     def step(self, local_pts):
-        """One pass: exchange + compute.  Returns (K, H) for rows [lo, hi)."""
-        full = allgather_points(local_pts, self.n_total, self.rank, self.world, self.device)
-        if self.compute is not None:
-            return self.compute(full.cpu().numpy(), self.lo, self.hi, self.k, self.eps)
-        self.run_device(full)
-        return self.download()
+        """One pass on host arrays: exchange + compute.  Returns (K, H) for rows [lo, hi)."""
+        local_pts = np.ascontiguousarray(local_pts, dtype=np.float32)
+        if local_pts.shape != (self.hi - self.lo, 3):
+            raise ValueError(f"rank {self.rank} must hold rows [{self.lo},{self.hi}) of the cloud, got {local_pts.shape}")
+        if self.compute is None:
+            self.upload_shard(local_pts)
+            self.run_device(self.end_exchange(self.begin_exchange(0)))
+            return self.download()
+        full = local_pts if self.world == 1 else self.exchange.allgather_host(local_pts, self.counts)
+        return self.compute(full, self.lo, self.hi, self.k, self.eps)
 
-    def run_device(self, full):
-        """Hand the gathered device buffer to the HIP path in place (no copy): ``full`` must stay unchanged
-        until the next call."""
-        import torch
-        torch.cuda.current_stream(full.device).synchronize()     # the collective ran on torch's stream
+    # ---- device buffers ---------------------------------------------------------------------------------------
+    def setup_device(self):
+        if self._bufs is None:
+            h = self.handle
+            self._send = h.device_alloc(max(int(self.counts[self.rank]), 1) * 4)
+            self._bufs = [h.device_alloc(self.n_total * 12) for _ in range(2 if self.world > 1 else 1)]
+        return self
+
+    def upload_shard(self, local_pts):
+        """This rank's rows of the next cloud, into its send buffer (after the previous exchange has read it)."""
+        self.setup_device()
+        local_pts = np.ascontiguousarray(local_pts, dtype=np.float32)
+        if local_pts.shape != (self.hi - self.lo, 3):
+            raise ValueError(f"rank {self.rank} must hold rows [{self.lo},{self.hi}) of the cloud, got {local_pts.shape}")
+        if self.world > 1:
+            self.handle.comm_synchronize()
+        if len(local_pts):
+            self.handle.device_upload(self._send if self.world > 1 else self._bufs[0], local_pts)
+
+    def begin_exchange(self, i):
+        """Start the all-gather of the resident shard into gather buffer ``i % 2``; returns a ticket."""
+        self.setup_device()
+        if self.world == 1:
+            return self._bufs[0]
+        return self.exchange.begin(self._send, self._bufs[i % 2], self.counts)
+
+    def end_exchange(self, ticket):
+        if self.world == 1:
+            return ticket
+        return self.exchange.end(ticket)
+
+    def run_device(self, full_ptr):
+        """Hand the gathered device buffer to the HIP path in place (no copy): it stays untouched until the next
+        exchange into it, which is ordered behind this pass on the device (pct_comm_allgather_f32)."""
         h = self.handle
-        h.use_points_device(full.data_ptr(), self.n_total)
+        h.use_points_device(full_ptr, self.n_total)
         h.set_query_range(self.lo, self.hi)
         h.curvature(self.k, self.eps or 0.0)
-
-    # A stream of clouds: the all-gather of the next cloud runs (RCCL's own stream) while the kernels of the
-    # current one run on the handle's stream.  Two gather buffers alternate.
-    def begin_exchange(self, local_dev, out):
-        """Start the all-gather of ``local_dev`` (this rank's (N/G,3) device shard) into ``out`` ((N,3) device)."""
-        import torch.distributed as dist
-        return dist.all_gather_into_tensor(out, local_dev, async_op=True)
-
-    def end_exchange(self, ticket, out):
-        """Block until the exchange started by ``begin_exchange`` has filled ``out``."""
-        import torch
-        ticket.wait()
-        if out.device.type == "cuda":
-            torch.cuda.current_stream(out.device).synchronize()
-        return out
 
     def download(self):
         _, K, H, _ = self.handle.get_fit(self.lo, self.hi, coefs=False, H2=False)
         return K, H
 
-
-def gather_to_rank0(K, H, n_total, rank, world):
-    """Host-side concatenation of the per-rank rows (outputs need no device collective)."""
-    import torch.distributed as dist
-    if world == 1:
-        return K, H
-    parts = [None] * world if rank == 0 else None
-    dist.gather_object((np.asarray(K), np.asarray(H)), parts, dst=0)
-    if rank != 0:
-        return None, None
-    return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts])
+    def close(self):
+        if self._bufs is not None:
+            h = self.handle
+            h.synchronize()
+            if self.world > 1:
+                h.comm_synchronize()
+            for p in [self._send] + self._bufs:
+                h.device_free(p)
+            self._send = self._bufs = None

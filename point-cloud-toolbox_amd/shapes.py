@@ -126,13 +126,17 @@ def egg_carton_random(n, seed=1234, amp=0.1, dtype=np.float32, lo=0, hi=None, wi
     return p, K, H
 
 
-def tile_cloud(base, n_tiles, pitch=0.25, lattice=(9, 8, 8), dtype=np.float32):
-    """Translated copies of ``base`` on a lattice (bunny x 557)."""
+def tile_cloud(base, n_tiles, pitch=0.25, lattice=(9, 8, 8), dtype=np.float32, only=None):
+    """Translated copies of ``base`` on a lattice (bunny x 557).  ``only``: the tiles to produce (a rank
+    of a sharded run builds just the ones its index range touches), concatenated in the given order."""
     base = np.asarray(base, dtype=np.float64)
     base = base - base.min(0)
-    out = np.empty((n_tiles * len(base), 3), dtype=dtype)
+    tiles = list(range(n_tiles)) if only is None else [int(t) for t in only]
+    out = np.empty((len(tiles) * len(base), 3), dtype=dtype)
     nx, ny, _ = lattice
-    for t in range(n_tiles):
+    for o, t in enumerate(tiles):
+        if not 0 <= t < n_tiles:
+            raise ValueError(f"tile {t} outside [0, {n_tiles})")
         off = np.array([t % nx, (t // nx) % ny, t // (nx * ny)], dtype=np.float64) * pitch
-        out[t * len(base):(t + 1) * len(base)] = (base + off).astype(dtype)
+        out[o * len(base):(o + 1) * len(base)] = (base + off).astype(dtype)
     return out

@@ -856,20 +856,57 @@ def test_neighbor_study_on_a_plane_converges_low(gpu):
 
 
 def test_distributed_step_on_one_rank(gpu, tmp_path):
-    """The multi-GPU code path of bench.py (RCCL all-gather into a device buffer, zero-copy hand-over, owned-range
-    sweep, double-buffered exchange) with a world of one rank.  Runs in a child process: torch has to be loaded
-    before libpct_hip.so there (one HIP runtime per process), which this test process cannot arrange any more."""
+    """The multi-GPU code path of bench.py -- RCCL communicator behind the C ABI (no PyTorch in the process), unique id
+    through the TCP rendezvous, all-gather into a device buffer on the exchange stream, zero-copy hand-over,
+    owned-range sweep, double-buffered exchange -- with a world of one rank, on BASELINE configs[3] (egg carton 5 M),
+    checked against the sampled reference golden."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PCT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
     for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(v, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--points-per-gpu", "200000"], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--config", "c4", "--verify",
+                        "--no-extras"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
-    assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0
+    assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0 and out["scaling"] == "strong"
+    assert out["verified"] == {"rows_checked": 2000, "ranks_seen": 1}
+    assert "RCCL" in out["config"]["parallelism"]
+
+
+def test_rccl_exchange_of_unequal_shards_in_process(gpu):
+    """pct_comm_* on one rank inside this process: communicator, all-gather (the equal-size and the per-rank-broadcast
+    form), device-side wait, reductions; the sharded driver gives what the plain handle gives."""
+    capi = gpu["capi"]
+    from point_cloud_toolbox_amd.dist import RcclExchange, ShardedCurvature
+    pts = gpu["shapes"].torus_random(30_001, seed=12)
+    h = capi.Handle(0)
+    ex = RcclExchange(h, 0, 1, addr="127.0.0.1", port=29547)
+    assert ex.allreduce([3.0, -1.0], "max").tolist() == [3.0, -1.0] and ex.allreduce([2.5], "sum").tolist() == [2.5]
+    ex.barrier()
+    send, recv = h.device_alloc(pts.nbytes), h.device_alloc(pts.nbytes)
+    h.device_upload(send, pts)
+    ex.end(ex.begin(send, recv, [pts.size]))
+    h.comm_synchronize()
+    back = np.empty_like(pts)
+    h.device_download(recv, back)
+    assert np.array_equal(back, pts)
+    h.device_free(send)
+    h.device_free(recv)
+    sc = ShardedCurvature(len(pts), 30, 0, 1, handle=h, exchange=ex)
+    K, H = sc.step(pts)
+    sc.close()
+    ref = capi.Handle(0)
+    ref.set_points(pts)
+    ref.curvature(30)
+    _, K0, H0, _ = ref.get_fit(0, len(pts), coefs=False, H2=False)
+    assert np.array_equal(K, K0) and np.array_equal(H, H0)
+    with pytest.raises(ValueError):
+        h.comm_init(0, 1, b"x" * 128)                    # one communicator per handle
+    ex.close()
+    ref.close()
+    h.close()
 
 
 @pytest.mark.parametrize("kind", ["blobs", "outliers", "shell_and_core", "quantised"])
