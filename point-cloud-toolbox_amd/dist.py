@@ -10,7 +10,7 @@ One process per GPU.  Any launcher that sets RANK / WORLD_SIZE / LOCAL_RANK / MA
 (``python -m torch.distributed.run`` is used as exactly that and nothing else).  The collective is RCCL over xGMI,
 called from ``libpct_hip.so`` (``pct_comm_*``, include/pct_hip.h) on the handle's exchange stream; rank 0 creates the
 RCCL unique id and :func:`rendezvous_unique_id` hands its 128 bytes to the other ranks over a TCP socket on
-``MASTER_ADDR:MASTER_PORT+1`` (``PCT_RDZV_PORT`` overrides the port).
+``MASTER_ADDR``, first free port of ``MASTER_PORT+1 .. +8`` (``PCT_RDZV_PORT`` overrides the first candidate).
 
 CPU tests cover ownership, concatenation and the double-buffered step pattern by injecting an exchange object with
 the same four methods (``tests/test_dist_gloo.py``: torch.distributed's gloo backend, world size 2) and a checker in
@@ -53,23 +53,37 @@ def _recv_exact(sock, n):
     return bytes(buf)
 
 
+RDZV_PORTS = 8          # rank 0 listens on the first free port of MASTER_PORT+1 .. +8; peers probe them in turn
+
+
 def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180.0):
     """Rank 0 calls ``make_id()`` (128 bytes) and serves them to the other ``world - 1`` ranks; every rank returns the
-    same bytes.  Each peer announces its rank first, so a stray connection cannot take a slot."""
+    same bytes.  Each peer announces itself (magic, rank) and the answer carries the magic back, so neither a stray
+    connection nor a foreign service on one of the candidate ports can be mistaken for the rendezvous."""
     if world == 1:
         return make_id()
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     if port is None:
         port = int(os.environ.get("PCT_RDZV_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 1
+    ports = [port + i for i in range(RDZV_PORTS)]
     deadline = time.monotonic() + timeout
     if rank == 0:
         payload = make_id()
         if len(payload) != 128:
             raise ValueError("the unique id must be 128 bytes")
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("", port))
-        srv.listen(world)
+        srv = None
+        for p in ports:
+            s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            try:
+                s.bind(("", p))
+                s.listen(world)
+                srv = s
+                break
+            except OSError:
+                s.close()
+        if srv is None:
+            raise OSError(f"rendezvous: none of the ports {ports[0]}..{ports[-1]} is free (set PCT_RDZV_PORT)")
         served = set()
         try:
             while len(served) < world - 1:
@@ -82,25 +96,29 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
                     conn.settimeout(10.0)
                     try:
                         magic, peer = struct.unpack("!4sI", _recv_exact(conn, 8))
-                    except (ConnectionError, socket.timeout, struct.error):
+                        if magic != b"PCT1" or not (0 < peer < world) or peer in served:
+                            continue
+                        conn.sendall(b"PCT1" + payload)
+                    except (ConnectionError, socket.timeout, struct.error, OSError):
                         continue
-                    if magic != b"PCT1" or not (0 < peer < world) or peer in served:
-                        continue
-                    conn.sendall(payload)
                     served.add(peer)
         finally:
             srv.close()
         return payload
     last = None
     while time.monotonic() < deadline:
-        try:
-            with socket.create_connection((addr, port), timeout=5.0) as s:
-                s.sendall(struct.pack("!4sI", b"PCT1", rank))
-                return _recv_exact(s, 128)
-        except (ConnectionRefusedError, ConnectionError, socket.timeout, OSError) as e:     # rank 0 is not listening yet
-            last = e
-            time.sleep(0.05)
-    raise TimeoutError(f"rendezvous: rank {rank} could not reach {addr}:{port}: {last}")
+        for p in ports:
+            try:
+                with socket.create_connection((addr, p), timeout=5.0) as s:
+                    s.settimeout(10.0)
+                    s.sendall(struct.pack("!4sI", b"PCT1", rank))
+                    answer = _recv_exact(s, 132)
+                    if answer[:4] == b"PCT1":
+                        return answer[4:]
+            except (ConnectionError, socket.timeout, OSError) as e:     # rank 0 is not listening (there) yet
+                last = e
+        time.sleep(0.05)
+    raise TimeoutError(f"rendezvous: rank {rank} could not reach {addr}:{ports[0]}..{ports[-1]}: {last}")
 
 
 # ------------------------------------------------------------------ exchange

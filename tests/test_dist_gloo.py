@@ -207,6 +207,40 @@ def _rdzv_worker(rank, world, port, q):
     q.put((rank, uid, len(calls)))
 
 
+def test_rendezvous_steps_past_an_occupied_port():
+    """torchrun's own store sits on MASTER_PORT; should MASTER_PORT+1 be taken as well, rank 0 listens on the next free
+    candidate and the peers find it (a foreign listener does not answer with the magic)."""
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    squatter = socket.socket()
+    squatter.bind(("127.0.0.1", port))
+    squatter.listen(4)
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import threading
+
+    def drop():                                   # the foreign service accepts and says nothing useful
+        squatter.settimeout(0.2)
+        end = __import__("time").monotonic() + 20
+        while __import__("time").monotonic() < end and any(p.is_alive() for p in procs):
+            try:
+                c, _ = squatter.accept()
+                c.close()
+            except socket.timeout:
+                pass
+    t = threading.Thread(target=drop)
+    t.start()
+    got = [q.get(timeout=60) for _ in range(2)]
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    t.join()
+    squatter.close()
+    assert got[0][1] == got[1][1] and len(got[0][1]) == 128
+
+
 @pytest.mark.parametrize("world", [2, 4, 8])
 def test_unique_id_rendezvous_reaches_every_rank(world):
     """What distributes the RCCL unique id: rank 0 generates it once, every rank ends up with the same 128 bytes --
