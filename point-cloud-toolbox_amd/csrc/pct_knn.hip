@@ -25,6 +25,7 @@
 #include "pct_internal.h"
 
 #include <math.h>
+#include <type_traits>
 
 namespace {
 
@@ -698,7 +699,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
 template <int R, bool EPS, bool PRE, bool PAIR = false, bool Q64 = false>
-__global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
+__global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
 #ifndef PCT_STAGE_CAP2
@@ -906,318 +907,339 @@ __global__ __launch_bounds__(64 * kFastWaves<R>) void k_knn_fast(KnnArgs a, cons
             }
             return (unsigned)fmin(lo2 * scale, 4294967294.0);
         };
-        for (int qi = 0; qi < nq; qi += 2) {
-            const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
-            const int qj = live_b ? qi + 1 : qi;
-            const int row_a = row0 + qi, row_b = row0 + qj;
-            float ax, ay, az, bx, by, bz;
-            if constexpr (!Q64) {
-                ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
-                ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
-                az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
-                bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
-                by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
-                bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
-            }
-            // Float64 cloud (Q64): the candidates are the float32-rounded points (the reference's tree data, pct:74) and
-            // my_q is the query ROUNDED to float32, so the pre-selection measures distances to a point that lies
-            // eq = |q64 - q32| away from the true query: every bound taken from it moves by eq (triangle inequality).
-            double qax, qay, qaz, qbx, qby, qbz, eq_a = 0.0, eq_b = 0.0;
-            if constexpr (Q64) {
-                const auto rl = [&](double v, int l) {
-                    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
-                };
-                qax = rl(my_qd.x, qi); qay = rl(my_qd.y, qi); qaz = rl(my_qd.z, qi);
-                qbx = rl(my_qd.x, qj); qby = rl(my_qd.y, qj); qbz = rl(my_qd.z, qj);
-                ax = (float)qax; ay = (float)qay; az = (float)qaz;         // == the float32 record of the point (k_pack_f64)
-                bx = (float)qbx; by = (float)qby; bz = (float)qbz;
-                eq_a = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qi));
-                eq_b = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qj));
-            } else {
-                qax = (double)ax; qay = (double)ay; qaz = (double)az; qbx = (double)bx; qby = (double)by; qbz = (double)bz;
-            }
-            // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
-            float ap_a[NB], ap_b[NB];
-#pragma unroll
-            for (int p2 = 0; p2 < NB / 2; ++p2) {
-                ap_a[2 * p2] = ap_a[2 * p2 + 1] = INFINITY;
-                ap_b[2 * p2] = ap_b[2 * p2 + 1] = INFINITY;
-                if (p2 * 128 < m) {
-                    const int sa = p2 * 128 + lane, sb = sa + 64;
-                    const float2v vx = {cand_x[sa], cand_x[sb]}, vy = {cand_y[sa], cand_y[sb]}, vz = {cand_z[sa], cand_z[sb]};
-                    {
-                        const float2v dx = vx - ax, dy = vy - ay, dz = vz - az;
-                        float2v d = dx * dx;
-                        d = __builtin_elementwise_fma(dy, dy, d);
-                        d = __builtin_elementwise_fma(dz, dz, d);
-                        ap_a[2 * p2] = d.x;
-                        ap_a[2 * p2 + 1] = d.y;
-                    }
-                    {
-                        const float2v dx = vx - bx, dy = vy - by, dz = vz - bz;
-                        float2v d = dx * dx;
-                        d = __builtin_elementwise_fma(dy, dy, d);
-                        d = __builtin_elementwise_fma(dz, dz, d);
-                        ap_b[2 * p2] = d.x;
-                        ap_b[2 * p2 + 1] = d.y;
-                    }
-                    n_step += 4;
+        // The per-query body is compiled once per number of staged batch PAIRS in use (NBP: 128 slots each): the loops
+        // over the batches are then straight code -- the "is this batch in use" tests were a scalar compare and a
+        // branch per batch, per loop, per query, on a kernel whose scalar unit is as busy as its vector units.  The
+        // smallest variant also serves the items with fewer pairs and keeps the tests (GUARD).
+        const auto pair_loop = [&](auto NBP_, auto GUARD_) {
+            constexpr int NBP = decltype(NBP_)::value, NBU = 2 * NBP;
+            constexpr bool GUARD = decltype(GUARD_)::value;
+            for (int qi = 0; qi < nq; qi += 2) {
+                const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
+                const int qj = live_b ? qi + 1 : qi;
+                const int row_a = row0 + qi, row_b = row0 + qj;
+                float ax, ay, az, bx, by, bz;
+                if constexpr (!Q64) {
+                    ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+                    ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+                    az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+                    bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
+                    by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
+                    bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
                 }
-            }
-            // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball ----------------------
-            float T_a = EPS ? eps2a : INFINITY, T_b = T_a;
-            if constexpr (EPS && Q64) {          // exact d < eps  =>  d' < eps + eq
-                const double ea = eps1 + eq_a, eb = eps1 + eq_b;
-                T_a = (float)fmin(ea * ea * (1.0 + 0x1p-18), 3.0e38);
-                T_b = (float)fmin(eb * eb * (1.0 + 0x1p-18), 3.0e38);
-            }
-            int tot_a = m, tot_b = m;
-            if constexpr (EPS) {
-                tot_a = tot_b = 0;
-#pragma unroll
-                for (int b = 0; b < NB; ++b)
-                    if ((b & ~1) * 64 < m) {
-                        tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < T_a));
-                        tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < T_b));
-                    }
-            }
-            int cnt_a = tot_a, cnt_b = tot_b;
-            bool ok_a = true, ok_b = live_b;              // still on the fast path
-            unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;
-            const bool need_a = tot_a > LIST, need_b = live_b && tot_b > LIST;
-            if (need_a || need_b) {
-                const float target = 0.5f * (float)(k + 1 + LIST);
-                float t0 = t_prev_f > 0.f ? t_prev_f : cell2f;
-                if (!(t0 < T_a)) t0 = 0.5f * T_a;
-                float lo_a = 0.f, hi_a = T_a, t_a = t0, lo_b = 0.f, hi_b = T_b, t_b = t0;
-                bool go_a = need_a, go_b = need_b, found_a = !need_a, found_b = !need_b;
-#pragma unroll 1
-                for (int trial = 0; trial < 16 && (go_a || go_b); ++trial) {
-                    int c_a = 0, c_b = 0;
-#pragma unroll
-                    for (int b = 0; b < NB; ++b)
-                        if ((b & ~1) * 64 < m) {
-                            c_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < t_a));
-                            c_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < t_b));
-                        }
-                    if (go_a) {
-                        if (c_a >= k + 1 && c_a <= LIST) { T_a = t_a; cnt_a = c_a; found_a = true; go_a = false; }
-                        else {
-                            if (c_a < k + 1) lo_a = t_a; else hi_a = t_a;
-                            float nt = c_a > 0 ? t_a * target * __builtin_amdgcn_rcpf((float)c_a) : 4.f * t_a;
-                            if (!(nt > lo_a && nt < hi_a)) nt = hi_a < INFINITY ? 0.5f * (lo_a + hi_a) : 2.f * lo_a;
-                            nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
-                            if (!(nt > lo_a && nt < hi_a)) go_a = false; else t_a = nt;   // no float left between
-                        }
-                    }
-                    if (go_b) {
-                        if (c_b >= k + 1 && c_b <= LIST) { T_b = t_b; cnt_b = c_b; found_b = true; go_b = false; }
-                        else {
-                            if (c_b < k + 1) lo_b = t_b; else hi_b = t_b;
-                            float nt = c_b > 0 ? t_b * target * __builtin_amdgcn_rcpf((float)c_b) : 4.f * t_b;
-                            if (!(nt > lo_b && nt < hi_b)) nt = hi_b < INFINITY ? 0.5f * (lo_b + hi_b) : 2.f * lo_b;
-                            nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
-                            if (!(nt > lo_b && nt < hi_b)) go_b = false; else t_b = nt;
-                        }
-                    }
-                }
-                if (need_a) {
-                    ok_a = found_a && T_a >= 1e-30f;
-                    if (ok_a) { t_prev_f = T_a; bkey_a = cut_key(T_a, eq_a); }
-                }
-                if (need_b) {
-                    ok_b = ok_b && found_b && T_b >= 1e-30f;
-                    if (ok_b) { t_prev_f = T_b; bkey_b = cut_key(T_b, eq_b); }
-                }
-                if (!ok_a) { push_redo(row_a, 3); T_a = 0.f; cnt_a = 0; }        // nothing passes, nothing is stored
-                if (!ok_b) { if (live_b) push_redo(row_b, 3); T_b = 0.f; cnt_b = 0; }
-                if (!ok_a && !ok_b) continue;
-            }
-            if (!live_b) { T_b = 0.f; cnt_b = 0; }
-            // ---- compact the slots of the survivors of both queries, then exact keys for them only ------------------
-            FastK<2 * R> both;                 // set 0 = query a (registers 0 .. R-1), set 1 = query b
-            float out_d[2 * R];                // float32 distance / sorted position of survivor lane + 64 r of each set
-            int out_p[2 * R];
-            const auto slot_to_pos = [&](int j) {
-                unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
-                if constexpr ((CAP / 64 + 7) / 8 > 1) {
-                    const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
-                    code = (j >> 9) ? hi : code;
-                }
-                return j + offc[(code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u];
-            };
-            {
-                int base_a = 0, base_b = 0;
-                wave_lds_sync();
-#pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    if ((b & ~1) * 64 < m) {
-                        const bool pa = ap_a[b] < T_a, pb = ap_b[b] < T_b;
-                        const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
-                        if (pa) pend[base_a + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0))] = (unsigned)(b * 64 + lane);
-                        if (pb) pend_b[base_b + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0))] = (unsigned short)(b * 64 + lane);
-                        base_a += (int)__popcll(ma);
-                        base_b += (int)__popcll(mb);
-                    }
-                }
-                wave_lds_sync();
-                // Survivor i's exact distance and sorted position are worked out here, by the lane that holds its
-                // coordinates anyway, and parked in that lane (out_d / out_p); after the sort the lane that ends up
-                // with list entry i fetches them with one cross-lane read each instead of recomputing them.
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r;
-                    unsigned e_a = kPadElem, e_b = kPadElem;
-                    const int ja = (int)pend[i] & (CAP_POW2 - 1), jb = (int)pend_b[i] & (CAP_POW2 - 1);   // stale beyond cnt: masked, unused
-                    out_p[r] = slot_to_pos(ja);           // cross-lane reads inside: every lane active here
-                    out_p[R + r] = slot_to_pos(jb);
-                    out_d[r] = out_d[R + r] = INFINITY;
-                    if (i < cnt_a) {
-                        const double dx = (double)cand_x[ja] - qax, dy = (double)cand_y[ja] - qay, dz = (double)cand_z[ja] - qaz;
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        out_d[r] = (float)sqrt(d2);
-                        if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
-                    }
-                    if (i < cnt_b) {
-                        const double dx = (double)cand_x[jb] - qbx, dy = (double)cand_y[jb] - qby, dz = (double)cand_z[jb] - qbz;
-                        const double d2 = (dx * dx + dy * dy) + dz * dz;
-                        out_d[R + r] = (float)sqrt(d2);
-                        if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
-                    }
-                    both.e[r] = e_a;
-                    both.e[R + r] = e_b;
-                }
-                wave_lds_sync();
-                fast_sort_sets<R, 2, 2>(both, sort_dir);
-                n_flush += 2;
-            }
-            // ---- proof obligations per query (see the single-query path below) -----------------------------------------
-            bool amb_a = false, amb_b = false, sparse_a = false, sparse_b = false;
-            bool col_a = false, col_b = false;        // equal keys among the first k+2 entries
-            {
-                unsigned tau_a, tau_b;         // element k of each list = the (k+1)-th nearest (padding if fewer exist)
-                {
-                    const int sl = k >> 6, src = k & 63;
-                    unsigned va = both.e[0], vb = both.e[R];
-#pragma unroll
-                    for (int r = 1; r < R; ++r)
-                        if (sl == r) { va = both.e[r]; vb = both.e[R + r]; }
-                    tau_a = (unsigned)__builtin_amdgcn_readlane((int)va, src);
-                    tau_b = (unsigned)__builtin_amdgcn_readlane((int)vb, src);
-                }
-                const unsigned g_a = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
-                const unsigned g_b = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj);
-                const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
-                const unsigned need_ka = min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key);
-                const unsigned need_kb = min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key);
-                sparse_a = need_ka > g_a;
-                sparse_b = need_kb > g_b;
-                amb_a |= need_ka > min(g_a, bkey_a);
-                amb_b |= need_kb > min(g_b, bkey_b);
-                amb_a |= tau_a != kPadElem && tk_a >= key_max - 1u;
-                amb_b |= tau_b != kPadElem && tk_b >= key_max - 1u;
-#pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    unsigned up_a = __shfl_down(both.e[r], 1), up_b = __shfl_down(both.e[R + r], 1);     // element i+1
-                    if (r + 1 < R) {
-                        const unsigned na = (unsigned)__builtin_amdgcn_readlane((int)both.e[r + 1 < R ? r + 1 : r], 0);
-                        const unsigned nb = (unsigned)__builtin_amdgcn_readlane((int)both.e[R + (r + 1 < R ? r + 1 : r)], 0);
-                        if (lane == 63) { up_a = na; up_b = nb; }
-                    } else if (lane == 63) {
-                        up_a = kPadElem;
-                        up_b = kPadElem;
-                    }
-                    const int i = lane + 64 * r;
-                    col_a |= i <= k && both.e[r] != kPadElem && up_a != kPadElem && ((both.e[r] ^ up_a) >> SLOT_BITS) == 0u;
-                    col_b |= i <= k && both.e[R + r] != kPadElem && up_b != kPadElem && ((both.e[R + r] ^ up_b) >> SLOT_BITS) == 0u;
-                }
-            }
-            if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a, sparse_a ? 1 : 3); ok_a = false; }
-            if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b, sparse_b ? 1 : 3); ok_b = false; }
-            // equal keys: ordered here by the exact values (order_equal_keys), not by the exact sweep
-            const auto pos_of_set = [&](unsigned at, int set) {
-                int p = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
-#pragma unroll
-                for (int r2 = 1; r2 < R; ++r2) {
-                    const int p2 = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
-                    if ((int)(at >> 6) == r2) p = p2;
-                }
-                return p;
-            };
-            // (the query is fetched from its lane again: keeping the six coordinates of the pair alive across the sort
-            // for this rare branch would cost the common path scalar registers it does not have)
-            const auto query_of = [&](int ql, double& x, double& y, double& z) {
+                // Float64 cloud (Q64): the candidates are the float32-rounded points (the reference's tree data, pct:74) and
+                // my_q is the query ROUNDED to float32, so the pre-selection measures distances to a point that lies
+                // eq = |q64 - q32| away from the true query: every bound taken from it moves by eq (triangle inequality).
+                double qax, qay, qaz, qbx, qby, qbz, eq_a = 0.0, eq_b = 0.0;
                 if constexpr (Q64) {
-                    x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.x), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.x), ql));
-                    y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.y), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.y), ql));
-                    z = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.z), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.z), ql));
+                    const auto rl = [&](double v, int l) {
+                        return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+                    };
+                    qax = rl(my_qd.x, qi); qay = rl(my_qd.y, qi); qaz = rl(my_qd.z, qi);
+                    qbx = rl(my_qd.x, qj); qby = rl(my_qd.y, qj); qbz = rl(my_qd.z, qj);
+                    ax = (float)qax; ay = (float)qay; az = (float)qaz;         // == the float32 record of the point (k_pack_f64)
+                    bx = (float)qbx; by = (float)qby; bz = (float)qbz;
+                    eq_a = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qi));
+                    eq_b = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qj));
                 } else {
-                    x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), ql));
-                    y = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), ql));
-                    z = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), ql));
+                    qax = (double)ax; qay = (double)ay; qaz = (double)az; qbx = (double)bx; qby = (double)by; qbz = (double)bz;
                 }
-            };
-            if (ok_a && __ballot(col_a) != 0ull) {
-                double ux, uy, uz;
-                query_of(qi, ux, uy, uz);
-                const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[0], a.pts,
-                    [&](unsigned at) {
-                        const int j = (int)pend[at] & (CAP_POW2 - 1);
-                        const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
-                        return (dx * dx + dy * dy) + dz * dz;
-                    },
-                    [&](unsigned at) { return pos_of_set(at, 0); });
-                if (!done) { push_redo(row_a, 3); ok_a = false; }
-            }
-            if (ok_b && __ballot(col_b) != 0ull) {
-                double ux, uy, uz;
-                query_of(qj, ux, uy, uz);
-                const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[R], a.pts,
-                    [&](unsigned at) {
-                        const int j = (int)pend_b[at] & (CAP_POW2 - 1);
-                        const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
-                        return (dx * dx + dy * dy) + dz * dz;
-                    },
-                    [&](unsigned at) { return pos_of_set(at, 1); });
-                if (!done) { push_redo(row_b, 3); ok_b = false; }
-            }
-            // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
+                // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
+                float ap_a[NBU], ap_b[NBU];
 #pragma unroll
-            for (int set = 0; set < 2; ++set) {
-                const bool ok = set == 0 ? ok_a : ok_b;
-                const int row = set == 0 ? row_a : row_b;
-                int found = 0;
-                char* const prow = (char*)(a.nbr_pos + (int64_t)row * a.pitch);      // uniform: scalar base + lane offset
-                char* const drow = (char*)(a.nbr_dist + (int64_t)row * a.pitch);
+                for (int p2 = 0; p2 < NBP; ++p2) {
+                    ap_a[2 * p2] = ap_a[2 * p2 + 1] = INFINITY;
+                    ap_b[2 * p2] = ap_b[2 * p2 + 1] = INFINITY;
+                    if (!GUARD || p2 * 128 < m) {
+                        const int sa = p2 * 128 + lane, sb = sa + 64;
+                        const float2v vx = {cand_x[sa], cand_x[sb]}, vy = {cand_y[sa], cand_y[sb]}, vz = {cand_z[sa], cand_z[sb]};
+                        {
+                            const float2v dx = vx - ax, dy = vy - ay, dz = vz - az;
+                            float2v d = dx * dx;
+                            d = __builtin_elementwise_fma(dy, dy, d);
+                            d = __builtin_elementwise_fma(dz, dz, d);
+                            ap_a[2 * p2] = d.x;
+                            ap_a[2 * p2 + 1] = d.y;
+                        }
+                        {
+                            const float2v dx = vx - bx, dy = vy - by, dz = vz - bz;
+                            float2v d = dx * dx;
+                            d = __builtin_elementwise_fma(dy, dy, d);
+                            d = __builtin_elementwise_fma(dz, dz, d);
+                            ap_b[2 * p2] = d.x;
+                            ap_b[2 * p2 + 1] = d.y;
+                        }
+                        n_step += 4;
+                    }
+                }
+                // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball ----------------------
+                float T_a = EPS ? eps2a : INFINITY, T_b = T_a;
+                if constexpr (EPS && Q64) {          // exact d < eps  =>  d' < eps + eq
+                    const double ea = eps1 + eq_a, eb = eps1 + eq_b;
+                    T_a = (float)fmin(ea * ea * (1.0 + 0x1p-18), 3.0e38);
+                    T_b = (float)fmin(eb * eb * (1.0 + 0x1p-18), 3.0e38);
+                }
+                int tot_a = m, tot_b = m;
+                if constexpr (EPS) {
+                    tot_a = tot_b = 0;
 #pragma unroll
-                for (int r = 0; r < R; ++r) {
-                    const int i = lane + 64 * r;
-                    const unsigned e = both.e[set * R + r];
-                    const bool real = e != kPadElem;
-                    const unsigned at = e & ((1u << SLOT_BITS) - 1u);       // survivor index: lane at & 63, register at >> 6
-                    float dist = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R])));
-                    int pos = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
+                    for (int b = 0; b < NBU; ++b)
+                        if (!GUARD || (b & ~1) * 64 < m) {
+                            tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < T_a));
+                            tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < T_b));
+                        }
+                }
+                int cnt_a = tot_a, cnt_b = tot_b;
+                bool ok_a = true, ok_b = live_b;              // still on the fast path
+                unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;
+                const bool need_a = tot_a > LIST, need_b = live_b && tot_b > LIST;
+                if (need_a || need_b) {
+                    const float target = 0.5f * (float)(k + 1 + LIST);
+                    float t0 = t_prev_f > 0.f ? t_prev_f : cell2f;
+                    if (!(t0 < T_a)) t0 = 0.5f * T_a;
+                    float lo_a = 0.f, hi_a = T_a, t_a = t0, lo_b = 0.f, hi_b = T_b, t_b = t0;
+                    bool go_a = need_a, go_b = need_b, found_a = !need_a, found_b = !need_b;
+#pragma unroll 1
+                    for (int trial = 0; trial < 16 && (go_a || go_b); ++trial) {
+                        int c_a = 0, c_b = 0;
+#pragma unroll
+                        for (int b = 0; b < NBU; ++b)
+                            if (!GUARD || (b & ~1) * 64 < m) {
+                                c_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < t_a));
+                                c_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < t_b));
+                            }
+                        if (go_a) {
+                            if (c_a >= k + 1 && c_a <= LIST) { T_a = t_a; cnt_a = c_a; found_a = true; go_a = false; }
+                            else {
+                                if (c_a < k + 1) lo_a = t_a; else hi_a = t_a;
+                                float nt = c_a > 0 ? t_a * target * __builtin_amdgcn_rcpf((float)c_a) : 4.f * t_a;
+                                if (!(nt > lo_a && nt < hi_a)) nt = hi_a < INFINITY ? 0.5f * (lo_a + hi_a) : 2.f * lo_a;
+                                nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
+                                if (!(nt > lo_a && nt < hi_a)) go_a = false; else t_a = nt;   // no float left between
+                            }
+                        }
+                        if (go_b) {
+                            if (c_b >= k + 1 && c_b <= LIST) { T_b = t_b; cnt_b = c_b; found_b = true; go_b = false; }
+                            else {
+                                if (c_b < k + 1) lo_b = t_b; else hi_b = t_b;
+                                float nt = c_b > 0 ? t_b * target * __builtin_amdgcn_rcpf((float)c_b) : 4.f * t_b;
+                                if (!(nt > lo_b && nt < hi_b)) nt = hi_b < INFINITY ? 0.5f * (lo_b + hi_b) : 2.f * lo_b;
+                                nt = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(nt)));
+                                if (!(nt > lo_b && nt < hi_b)) go_b = false; else t_b = nt;
+                            }
+                        }
+                    }
+                    if (need_a) {
+                        ok_a = found_a && T_a >= 1e-30f;
+                        if (ok_a) { t_prev_f = T_a; bkey_a = cut_key(T_a, eq_a); }
+                    }
+                    if (need_b) {
+                        ok_b = ok_b && found_b && T_b >= 1e-30f;
+                        if (ok_b) { t_prev_f = T_b; bkey_b = cut_key(T_b, eq_b); }
+                    }
+                    if (!ok_a) { push_redo(row_a, 3); T_a = 0.f; cnt_a = 0; }        // nothing passes, nothing is stored
+                    if (!ok_b) { if (live_b) push_redo(row_b, 3); T_b = 0.f; cnt_b = 0; }
+                    if (!ok_a && !ok_b) continue;
+                }
+                if (!live_b) { T_b = 0.f; cnt_b = 0; }
+                // ---- compact the slots of the survivors of both queries, then exact keys for them only ------------------
+                FastK<2 * R> both;                 // set 0 = query a (registers 0 .. R-1), set 1 = query b
+                float out_d[2 * R];                // float32 distance / sorted position of survivor lane + 64 r of each set
+                int out_p[2 * R];
+                const auto slot_to_pos = [&](int j) {
+                    unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[0]);
+                    if constexpr ((CAP / 64 + 7) / 8 > 1) {
+                        const unsigned hi = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code[1]);
+                        code = (j >> 9) ? hi : code;
+                    }
+                    return j + offc[(code >> ((((unsigned)j >> 6) & 7u) << 2)) & 15u];
+                };
+                {
+                    int base_a = 0, base_b = 0;
+                    wave_lds_sync();
+#pragma unroll
+                    for (int b = 0; b < NBU; ++b) {
+                        if (!GUARD || (b & ~1) * 64 < m) {
+                            const bool pa = ap_a[b] < T_a, pb = ap_b[b] < T_b;
+                            const unsigned long long ma = __builtin_amdgcn_ballot_w64(pa), mb = __builtin_amdgcn_ballot_w64(pb);
+                            if (pa) pend[base_a + __builtin_amdgcn_mbcnt_hi((unsigned)(ma >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)ma, 0))] = (unsigned)(b * 64 + lane);
+                            if (pb) pend_b[base_b + __builtin_amdgcn_mbcnt_hi((unsigned)(mb >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mb, 0))] = (unsigned short)(b * 64 + lane);
+                            base_a += (int)__popcll(ma);
+                            base_b += (int)__popcll(mb);
+                        }
+                    }
+                    wave_lds_sync();
+                    // Survivor i's exact distance and sorted position are worked out here, by the lane that holds its
+                    // coordinates anyway, and parked in that lane (out_d / out_p); after the sort the lane that ends up
+                    // with list entry i fetches them with one cross-lane read each instead of recomputing them.
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        unsigned e_a = kPadElem, e_b = kPadElem;
+                        const int ja = (int)pend[i] & (CAP_POW2 - 1), jb = (int)pend_b[i] & (CAP_POW2 - 1);   // stale beyond cnt: masked, unused
+                        out_p[r] = slot_to_pos(ja);           // cross-lane reads inside: every lane active here
+                        out_p[R + r] = slot_to_pos(jb);
+                        out_d[r] = out_d[R + r] = INFINITY;
+                        if (i < cnt_a) {
+                            const double dx = (double)cand_x[ja] - qax, dy = (double)cand_y[ja] - qay, dz = (double)cand_z[ja] - qaz;
+                            const double d2 = (dx * dx + dy * dy) + dz * dz;
+                            out_d[r] = (float)sqrt(d2);
+                            if (!EPS || d2 < eps2) e_a = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
+                        }
+                        if (i < cnt_b) {
+                            const double dx = (double)cand_x[jb] - qbx, dy = (double)cand_y[jb] - qby, dz = (double)cand_z[jb] - qbz;
+                            const double d2 = (dx * dx + dy * dy) + dz * dz;
+                            out_d[R + r] = (float)sqrt(d2);
+                            if (!EPS || d2 < eps2) e_b = (min((unsigned)(d2 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)i;
+                        }
+                        both.e[r] = e_a;
+                        both.e[R + r] = e_b;
+                    }
+                    wave_lds_sync();
+                    fast_sort_sets<R, 2, 2>(both, sort_dir);
+                    n_flush += 2;
+                }
+                // ---- proof obligations per query (see the single-query path below) -----------------------------------------
+                bool amb_a = false, amb_b = false, sparse_a = false, sparse_b = false;
+                bool col_a = false, col_b = false;        // equal keys among the first k+2 entries
+                {
+                    unsigned tau_a, tau_b;         // element k of each list = the (k+1)-th nearest (padding if fewer exist)
+                    {
+                        const int sl = k >> 6, src = k & 63;
+                        unsigned va = both.e[0], vb = both.e[R];
+#pragma unroll
+                        for (int r = 1; r < R; ++r)
+                            if (sl == r) { va = both.e[r]; vb = both.e[R + r]; }
+                        tau_a = (unsigned)__builtin_amdgcn_readlane((int)va, src);
+                        tau_b = (unsigned)__builtin_amdgcn_readlane((int)vb, src);
+                    }
+                    const unsigned g_a = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
+                    const unsigned g_b = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj);
+                    const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
+                    const unsigned need_ka = min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key);
+                    const unsigned need_kb = min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key);
+                    sparse_a = need_ka > g_a;
+                    sparse_b = need_kb > g_b;
+                    amb_a |= need_ka > min(g_a, bkey_a);
+                    amb_b |= need_kb > min(g_b, bkey_b);
+                    amb_a |= tau_a != kPadElem && tk_a >= key_max - 1u;
+                    amb_b |= tau_b != kPadElem && tk_b >= key_max - 1u;
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        unsigned up_a = __shfl_down(both.e[r], 1), up_b = __shfl_down(both.e[R + r], 1);     // element i+1
+                        if (r + 1 < R) {
+                            const unsigned na = (unsigned)__builtin_amdgcn_readlane((int)both.e[r + 1 < R ? r + 1 : r], 0);
+                            const unsigned nb = (unsigned)__builtin_amdgcn_readlane((int)both.e[R + (r + 1 < R ? r + 1 : r)], 0);
+                            if (lane == 63) { up_a = na; up_b = nb; }
+                        } else if (lane == 63) {
+                            up_a = kPadElem;
+                            up_b = kPadElem;
+                        }
+                        const int i = lane + 64 * r;
+                        col_a |= i <= k && both.e[r] != kPadElem && up_a != kPadElem && ((both.e[r] ^ up_a) >> SLOT_BITS) == 0u;
+                        col_b |= i <= k && both.e[R + r] != kPadElem && up_b != kPadElem && ((both.e[R + r] ^ up_b) >> SLOT_BITS) == 0u;
+                    }
+                }
+                if (ok_a && __ballot(amb_a) != 0ull) { push_redo(row_a, sparse_a ? 1 : 3); ok_a = false; }
+                if (ok_b && __ballot(amb_b) != 0ull) { push_redo(row_b, sparse_b ? 1 : 3); ok_b = false; }
+                // equal keys: ordered here by the exact values (order_equal_keys), not by the exact sweep
+                const auto pos_of_set = [&](unsigned at, int set) {
+                    int p = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
 #pragma unroll
                     for (int r2 = 1; r2 < R; ++r2) {
-                        const float d2nd = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R + r2])));
-                        const int p2nd = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
-                        if ((int)(at >> 6) == r2) { dist = d2nd; pos = p2nd; }
+                        const int p2 = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
+                        if ((int)(at >> 6) == r2) p = p2;
                     }
-                    if (ok && i >= 1 && i <= k) {
-                        const unsigned off = (unsigned)(i - 1) * 4u;
-                        *(int*)(prow + off) = real ? pos : -1;
-                        *(float*)(drow + off) = real ? dist : INFINITY;
-                        found += real;
+                    return p;
+                };
+                // (the query is fetched from its lane again: keeping the six coordinates of the pair alive across the sort
+                // for this rare branch would cost the common path scalar registers it does not have)
+                const auto query_of = [&](int ql, double& x, double& y, double& z) {
+                    if constexpr (Q64) {
+                        x = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.x), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.x), ql));
+                        y = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.y), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.y), ql));
+                        z = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(my_qd.z), ql), __builtin_amdgcn_readlane(__double2loint(my_qd.z), ql));
+                    } else {
+                        x = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), ql));
+                        y = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), ql));
+                        z = (double)__int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), ql));
                     }
+                };
+                if (ok_a && __ballot(col_a) != 0ull) {
+                    double ux, uy, uz;
+                    query_of(qi, ux, uy, uz);
+                    const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[0], a.pts,
+                        [&](unsigned at) {
+                            const int j = (int)pend[at] & (CAP_POW2 - 1);
+                            const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
+                            return (dx * dx + dy * dy) + dz * dz;
+                        },
+                        [&](unsigned at) { return pos_of_set(at, 0); });
+                    if (!done) { push_redo(row_a, 3); ok_a = false; }
                 }
-                if (ok) {
-                    if (a.nbr_cnt) {
-                        for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
-                        if (lane == 0) a.nbr_cnt[row] = found;
+                if (ok_b && __ballot(col_b) != 0ull) {
+                    double ux, uy, uz;
+                    query_of(qj, ux, uy, uz);
+                    const bool done = order_equal_keys<R, SLOT_BITS>(&both.e[R], a.pts,
+                        [&](unsigned at) {
+                            const int j = (int)pend_b[at] & (CAP_POW2 - 1);
+                            const double dx = (double)cand_x[j] - ux, dy = (double)cand_y[j] - uy, dz = (double)cand_z[j] - uz;
+                            return (dx * dx + dy * dy) + dz * dz;
+                        },
+                        [&](unsigned at) { return pos_of_set(at, 1); });
+                    if (!done) { push_redo(row_b, 3); ok_b = false; }
+                }
+                // ---- store: slot -> sorted position (cross-lane reads with every lane active), exact distance ----------------
+#pragma unroll
+                for (int set = 0; set < 2; ++set) {
+                    const bool ok = set == 0 ? ok_a : ok_b;
+                    const int row = set == 0 ? row_a : row_b;
+                    int found = 0;
+                    char* const prow = (char*)(a.nbr_pos + (int64_t)row * a.pitch);      // uniform: scalar base + lane offset
+                    char* const drow = (char*)(a.nbr_dist + (int64_t)row * a.pitch);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const int i = lane + 64 * r;
+                        const unsigned e = both.e[set * R + r];
+                        const bool real = e != kPadElem;
+                        const unsigned at = e & ((1u << SLOT_BITS) - 1u);       // survivor index: lane at & 63, register at >> 6
+                        float dist = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R])));
+                        int pos = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R]);
+#pragma unroll
+                        for (int r2 = 1; r2 < R; ++r2) {
+                            const float d2nd = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, __float_as_int(out_d[set * R + r2])));
+                            const int p2nd = __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_p[set * R + r2]);
+                            if ((int)(at >> 6) == r2) { dist = d2nd; pos = p2nd; }
+                        }
+                        if (ok && i >= 1 && i <= k) {
+                            const unsigned off = (unsigned)(i - 1) * 4u;
+                            *(int*)(prow + off) = real ? pos : -1;
+                            *(float*)(drow + off) = real ? dist : INFINITY;
+                            found += real;
+                        }
                     }
-                    if (a.row_done && lane == 0) a.row_done[row] = 1;
+                    if (ok) {
+                        if (a.nbr_cnt) {
+                            for (int o = 32; o > 0; o >>= 1) found += __shfl_xor(found, o);
+                            if (lane == 0) a.nbr_cnt[row] = found;
+                        }
+                        if (a.row_done && lane == 0) a.row_done[row] = 1;
+                    }
                 }
             }
+        };
+        {
+            using std::integral_constant;
+            constexpr int PAIRS = NB / 2, LOW = PAIRS / 2;          // R = 1: 4 pairs, variants 2 | 3 | 4; R = 2: 6 pairs, 3 | 4 | 5 | 6
+            const int nbp = (m + 127) >> 7;
+#ifdef PCT_NO_NBP                                                   // tuning aid: one guarded body as before
+            if (nbp >= 0) pair_loop(integral_constant<int, PAIRS>{}, integral_constant<bool, true>{});
+            else
+#endif
+            if (nbp <= LOW) pair_loop(integral_constant<int, LOW>{}, integral_constant<bool, true>{});
+            else if (nbp == LOW + 1) pair_loop(integral_constant<int, LOW + 1>{}, integral_constant<bool, false>{});
+            else if (PAIRS > LOW + 2 && nbp == LOW + 2) pair_loop(integral_constant<int, (PAIRS > LOW + 2 ? LOW + 2 : PAIRS)>{}, integral_constant<bool, false>{});
+            else pair_loop(integral_constant<int, PAIRS>{}, integral_constant<bool, false>{});
         }
     } else
     for (int qi = 0; qi < nq; ++qi) {
