@@ -93,7 +93,7 @@ void pct_destroy(pct_ctx* ctx) {
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
                       &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
-                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4, &ctx->fit_flag};
+                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4, &ctx->fit_flag, &ctx->lvl_src};
     for (pct_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
@@ -202,7 +202,8 @@ int pct_set_stats(pct_ctx* ctx, int32_t enable) {
 }
 
 // neighbour sweep without timing bookkeeping; events 2..4 bracket grid / sweep
-static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_fit = false) {
+    ctx->levels_fitted = false;
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
     if (k < 1 || k > 127) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,127]", k);
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
@@ -219,7 +220,10 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     ctx->tm.levels = 0;
     if (algo == PCT_KNN_GRID_LEVELS) {
         PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        PCT_TRY(pct_knn_levels(ctx, k, eps));
+        ctx->levels_fuse_fit = fuse_fit;
+        const int lst = pct_knn_levels(ctx, k, eps);
+        ctx->levels_fuse_fit = false;
+        PCT_TRY(lst);
         PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
         PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
         ctx->tm.knn_launches = ctx->tm.levels;
@@ -298,7 +302,7 @@ int pct_fit(pct_ctx* ctx) {
     PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
-    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 256);
+    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 2048);
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
     ctx->fit_valid = true;
     ctx->fit_cloud_aligned = true;
@@ -309,7 +313,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     PCT_TRY(begin_call(ctx));
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool again = false;
-        PCT_TRY(run_knn(ctx, k, eps, algo));
+        PCT_TRY(run_knn(ctx, k, eps, algo, true));
         PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         PCT_TRY(pct_launch_fit_table(ctx));
         PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
@@ -320,7 +324,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
     }
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
-    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 256);
+    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 2048);
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
     ctx->fit_valid = true;
@@ -429,7 +433,7 @@ int pct_fit_indices(pct_ctx* ctx, const int32_t* idx, const int32_t* count, cons
     PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
-    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 256);
+    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 2048);
     ctx->fit_rows = rows;
     ctx->fit_row_order = false;
     ctx->fit_valid = true;

@@ -338,7 +338,8 @@ __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4
     int c = (cz * g.ny + cy) * g.nx + cx;
     cell_of[i] = c;
     // level passes (pct_levels.hip) own the still unanswered points whose wanted cell edge (log2) lies in a band
-    const bool owned = own_want ? (own_want[i] >= own_lo && own_want[i] < own_hi) : (i >= q_begin && i < q_end);
+    const float want = own_want ? own_want[__float_as_int(p.w)] : 0.f;
+    const bool owned = own_want ? (want >= own_lo && want < own_hi) : (i >= q_begin && i < q_end);
     if (owned) {
         rank_of[i] = atomicAdd(&cell_own[c], 1);
     } else {
@@ -350,6 +351,56 @@ __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4
             return;
         }
         rank_of[i] = atomicAdd(&cell_oth[c], 1) | (int)0x80000000;
+    }
+}
+
+// The same for the later passes of the density-adaptive sweep (pct_levels.hip), whose cells are sized for ONE band of
+// densities while every point is still a candidate: the denser part of the cloud then piles into a handful of cells
+// and its atomics serialise at the memory side (~88 per microsecond and address: a 1/r^2 scan spent 1-2 ms per pass
+// there).  These passes read the points in the cell order of the first pass, so the lanes of a wave mostly share
+// their cell: one atomic per distinct (cell, class) of the wave, ranks handed out by bit counts.
+__global__ __launch_bounds__(kBlock) void k_hist_agg(const float4* __restrict__ pts4, int64_t n, pct_grid g,
+                                                     const float* __restrict__ own_want, float own_lo, float own_hi, int skip_outside,
+                                                     int* __restrict__ cell_of, int* __restrict__ rank_of,
+                                                     int* __restrict__ cell_own, int* __restrict__ cell_oth) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int key = -1;                       // 2 * cell + (owned ? 1 : 0); -1 = not counted
+    if (i < n) {
+        const float4 p = pts4[i];
+        bool inside = true;
+        if (skip_outside) {
+            const double fx = floor(((double)p.x - g.ox) * g.inv_cell), fy = floor(((double)p.y - g.oy) * g.inv_cell),
+                         fz = floor(((double)p.z - g.oz) * g.inv_cell);
+            inside = !(fx < 0 || fx >= g.nx || fy < 0 || fy >= g.ny || fz < 0 || fz >= g.nz);
+        }
+        if (inside) {
+            const int cx = cell_coord((double)p.x, g.ox, g.inv_cell, g.nx);
+            const int cy = cell_coord((double)p.y, g.oy, g.inv_cell, g.ny);
+            const int cz = cell_coord((double)p.z, g.oz, g.inv_cell, g.nz);
+            const int c = (cz * g.ny + cy) * g.nx + cx;
+            const float w = own_want[__float_as_int(p.w)];
+            const bool owned = w >= own_lo && w < own_hi;
+            // a cell that already holds far more candidates than the sweep can stage overflows every stencil it is
+            // part of: further candidates in it are dead weight (its count stays above the staging capacity)
+            if (owned || !skip_outside || __builtin_nontemporal_load(&cell_oth[c]) <= 2048) key = 2 * c + (owned ? 1 : 0);
+        }
+    }
+    int rank = 0;
+    unsigned long long todo = __builtin_amdgcn_ballot_w64(key >= 0);
+    while (todo) {
+        const int leader = (int)__builtin_ctzll(todo);
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
+        const unsigned long long same = __builtin_amdgcn_ballot_w64(key == k0);
+        int base = 0;
+        if (lane == leader) base = atomicAdd((k0 & 1) ? &cell_own[k0 >> 1] : &cell_oth[k0 >> 1], (int)__popcll(same));
+        base = __builtin_amdgcn_readlane(base, leader);
+        if (key == k0) rank = base + (int)__popcll(same & ((1ull << lane) - 1ull));
+        todo &= ~same;
+    }
+    if (i < n) {
+        cell_of[i] = key < 0 ? -1 : key >> 1;
+        if (key >= 0) rank_of[i] = (key & 1) ? rank : (rank | (int)0x80000000);
     }
 }
 
@@ -500,8 +551,9 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ p
     } else {
         pos = cell_start[c] + cell_own[c] + (r & 0x7fffffff);
     }
-    sorted4[pos] = pts4[i];
-    if (pts4d) sorted4d[pos] = pts4d[i];
+    const float4 p = pts4[i];
+    sorted4[pos] = p;
+    if (pts4d) sorted4d[pos] = pts4d[__float_as_int(p.w)];      // float64 records stay in public order (never culled)
 }
 
 __global__ __launch_bounds__(256) void k_gather_int(const int* __restrict__ map, int* __restrict__ io, int64_t n) {
@@ -738,6 +790,15 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // trip less per build.
     bool spec = !try_cull && !own_flag && !ctx->level_mode && ctx->hint_edge > 0 && ctx->spec_valid && ctx->spec_n == ctx->n &&
                 !getenv("PCT_NO_SPEC");
+    // later passes of the density-adaptive sweep: the points in the cell order of its first pass, and that pass's box
+    const bool from_base = own_flag && ctx->lvl_src_valid;
+    if (from_base) {
+        for (int a = 0; a < 6; ++a) bbox[a] = ctx->lvl_bbox[a];
+        red = PackRed{};
+        ctx->n_grid = ctx->n;
+        ctx->g_begin = 0;
+        ctx->culled = false;
+    } else
     if (try_cull) {
         PCT_TRY(pack_near_owned(ctx, target, bbox, &red, &kept_box));
         if (ctx->n_grid < (int64_t)k + 1) {
@@ -828,8 +889,14 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
             PCT_TRY(pct_reserve(ctx, &ctx->cell_oth, (size_t)g.ncell * sizeof(int)));
             PCT_HIP(ctx, hipMemsetAsync(ctx->cell_oth.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
         }
+        const float4* src = from_base ? (const float4*)ctx->lvl_src.p : (const float4*)ctx->pts4.p;
+        if (from_base)
+            hipLaunchKernelGGL(k_hist_agg, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream, src, n, g, own_flag, ctx->own_lo,
+                               ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p, (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p,
+                               (int*)ctx->cell_oth.p);
+        else
         hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
+                           src, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
@@ -846,7 +913,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
         hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
-                           (const float4*)ctx->pts4.p, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
+                           src, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
                            (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
                            g_begin, (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
                            ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
@@ -900,6 +967,8 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     if (getenv("PCT_GRID_DEBUG"))
         fprintf(stderr, "[grid] box [%g %g %g]-[%g %g %g] edge %g dims %d x %d x %d = %lld cells, %d passes, occupancy %.1f, items %d\n", bbox[0],
                 bbox[1], bbox[2], bbox[3], bbox[4], bbox[5], g.cell, g.nx, g.ny, g.nz, (long long)g.ncell, iters, m_last, tot.y);
+    if (ctx->level_mode && !own_flag)                    // first pass of a density-adaptive sweep: its (trimmed) box serves the later ones
+        for (int a2 = 0; a2 < 6; ++a2) ctx->lvl_bbox[a2] = bbox[a2];
     ctx->grid = g;
     ctx->tm.grid_iters += iters;
     ctx->tm.cells = g.ncell;

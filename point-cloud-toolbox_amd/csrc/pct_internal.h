@@ -67,6 +67,11 @@ struct pct_ctx {
     int64_t own_count = 0;
     double level_edge = 0;          // > 0: first cell edge of this pass
     bool level_mode = false;        // a density-adaptive sweep is in progress (rows answered are recorded in row_done)
+    bool levels_fuse_fit = false;   // pct_curvature: every pass fits the rows it answered (in its own cell order)
+    bool levels_fitted = false;     // ... and did: pct_launch_fit_table has nothing left to do
+    pct_buf lvl_src;                // float4 (n): the points in the cell order of the first pass (input of the later passes' builds)
+    bool lvl_src_valid = false;
+    float lvl_bbox[6] = {0, 0, 0, 0, 0, 0};
     pct_buf row_done;               // int32 (rows of the pass)
     pct_buf redo_m;                 // int32, parallel to redo: stencil population of the row's item
     pct_buf flag_buf;               // float (n): wanted log2 cell edge of every point still unanswered (NaN = answered)
@@ -103,7 +108,7 @@ struct pct_ctx {
     pct_buf red;        // small reduction scratch
     // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
     // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
-    // [192,256) sweep counters  [256,264) rows of the last fit that went to k_fit_svd
+    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd
     unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;
@@ -192,6 +197,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);
 // fit (pct_fit.hip)
 int pct_launch_fit_table(pct_ctx* ctx);
+int pct_launch_fit_pass(pct_ctx* ctx, int64_t rows);
 int pct_launch_fit_rows(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d_cnt,
                         const int64_t* d_query, int64_t rows, int32_t k, int32_t pitch,
                         float* d_coefs, float* d_K, float* d_H, float* d_H2, bool sorted_space);

@@ -55,7 +55,7 @@ struct KnnArgs {
     float* nbr_dist;
     int* nbr_cnt;             // nullable
     int* row_done;            // nullable: set to 1 for every row a kernel has answered (level passes)
-    int* redo_m;              // nullable, parallel to the redo list: candidates the stencil of the row's item held
+    int* redo_m;              // nullable (level passes), one slot per table row: why << 29 | candidates the stencil of the row's item held
     int stats;                // collect the counters below (off by default)
     unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries [5] queries beyond the culling limits (always counted)
 };
@@ -691,10 +691,9 @@ template <int R> constexpr int kFastWaves = PCT_FAST_WAVES;
 // exact squared distance >= T (1 - 2^-20): the query is accepted only if its (k+1)-th exact key lies below that.
 typedef float float2v __attribute__((ext_vector_type(2)));
 
-// Level passes (pct_levels.hip) want to know WHY a row went to the redo list: the two top payload bits of an entry
-// carry 1 = the stencil cannot vouch for the answer (cells too small for this query), 2 = the stencil overflowed the
-// staging area (cells too large), 3 = anything else.  Plain sweeps store the bare row.
-#define PCT_REDO_ENTRY(row, why) (a.row_done ? ((row) | ((why) << 29)) : (row))
+// Level passes (pct_levels.hip) want to know WHY a row was not answered: 1 = the stencil cannot vouch for the answer
+// (cells too small for this query), 2 = the stencil overflowed the staging area (cells too large), 3 = anything else;
+// they get it, with the stencil population, in the row's slot of redo_m.  Plain sweeps append the bare row to the list.
 
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
@@ -791,17 +790,27 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
         redo_why_hi |= (unsigned long long)((why >> 1) & 1) << q;
     };
 
-    if (m > CAP) {
+    // (a pass of the density-adaptive sweep, no eps bound: a stencil that does not even hold k+1 points cannot answer
+    // any of the item's queries -- every point is binned somewhere -- so the item is classified "cells too small"
+    // without being swept)
+    const bool hopeless = !EPS && a.row_done != nullptr && m < a.k + 1;
+    if (m > CAP || hopeless) {
         // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
+        if (a.row_done) {
+            // passes of the density-adaptive sweep keep no list: reason and stencil population go to the row's own
+            // slot (a cloud of very uneven density fails hundreds of thousands of one-query items per pass, and as
+            // many increments of ONE counter serialise for milliseconds)
+            if (lane < nq) a.redo_m[row0 + lane] = ((hopeless ? 1 : 2) << 29) | min(m, (1 << 29) - 1);
+            return;
+        }
         int base = 0;
         if (lane == 0) base = atomicAdd(redo_count, nq);
         base = __builtin_amdgcn_readfirstlane(base);
         if (lane < nq) {
-            redo[base + lane] = PCT_REDO_ENTRY(row0 + lane, 2);
-            if (a.redo_m) a.redo_m[base + lane] = m;
+            redo[base + lane] = row0 + lane;
         }
         if (a.stats && lane == 0) {
-            atomicAdd(&a.counters[1], 1ull);
+            if (!hopeless) atomicAdd(&a.counters[1], 1ull);
             atomicAdd(&a.counters[4], (unsigned long long)nq);
         }
         return;
@@ -1537,14 +1546,16 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
     }
     if (redo_mask) {
         const int cnt = (int)__popcll(redo_mask);
-        int base = 0;
-        if (lane == 0) base = atomicAdd(redo_count, cnt);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if ((redo_mask >> lane) & 1ull) {
-            const int at = base + (int)__popcll(redo_mask & ((1ull << lane) - 1ull));
-            const int why = (int)((redo_why_lo >> lane) & 1ull) | ((int)((redo_why_hi >> lane) & 1ull) << 1);
-            redo[at] = PCT_REDO_ENTRY(row0 + lane, why);
-            if (a.redo_m) a.redo_m[at] = m;
+        if (a.row_done) {
+            if ((redo_mask >> lane) & 1ull) {
+                const int why = (int)((redo_why_lo >> lane) & 1ull) | ((int)((redo_why_hi >> lane) & 1ull) << 1);
+                a.redo_m[row0 + lane] = (why << 29) | min(m, (1 << 29) - 1);
+            }
+        } else {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(redo_count, cnt);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if ((redo_mask >> lane) & 1ull) redo[base + (int)__popcll(redo_mask & ((1ull << lane) - 1ull))] = row0 + lane;
         }
         n_redo += (unsigned long long)cnt;
     }

@@ -55,17 +55,16 @@ __global__ __launch_bounds__(256) void k_merge_rows(const float4* __restrict__ s
 }
 
 // rows the pass left unanswered: update the bracket of the query's wanted edge and the wanted edge itself
-__global__ __launch_bounds__(256) void k_classify(const int* __restrict__ redo, const int* __restrict__ redo_m,
-                                                  const int* __restrict__ redo_count,
+__global__ __launch_bounds__(256) void k_classify(const int* __restrict__ row_done, const int* __restrict__ redo_m, int64_t n_rows,
                                                   const float4* __restrict__ sorted4, const int* __restrict__ owned_pos,
                                                   float log_edge, float target,
                                                   float* __restrict__ want, float2* __restrict__ bracket) {
-    const int n = *redo_count;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-        const unsigned e = (unsigned)redo[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows; i += (int64_t)gridDim.x * 256) {
+        if (row_done[i]) continue;
+        const unsigned e = (unsigned)redo_m[i];      // the row's own slot: why << 29 | stencil population
         const int why = (int)(e >> 29);
-        const int pub = pub_of(sorted4, owned_pos[e & 0x1FFFFFFFu]);
-        const float pop = (float)redo_m[i];          // candidates the 27-cell stencil of the query's item held
+        const int pub = pub_of(sorted4, owned_pos[i]);
+        const float pop = (float)(e & 0x1FFFFFFFu);  // candidates the 27-cell stencil of the query's item held
         float2 b = bracket[pub];
         float w = kWantExact;
         // a failure that tells nothing new (the pass edge lay outside the bracket already known) ends the search
@@ -210,12 +209,13 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
         PCT_TRY(pct_launch_knn_grid(ctx, k, eps, exact, exact ? 0 : 1));
         if (!exact) {
             // the stencil of a well-sized pass holds about 11 cells' worth of points on a surface
-            hipLaunchKernelGGL(k_classify, dim3(1024), dim3(256), 0, ctx->stream, (const int*)ctx->redo.p, (const int*)ctx->redo_m.p,
-                               (const int*)ctx->counters.p + 14, (const float4*)ctx->sorted4.p, (const int*)ctx->owned_pos.p,
+            hipLaunchKernelGGL(k_classify, dim3(1024), dim3(256), 0, ctx->stream, (const int*)ctx->row_done.p, (const int*)ctx->redo_m.p,
+                               owned, (const float4*)ctx->sorted4.p, (const int*)ctx->owned_pos.p,
                                (float)log2(ctx->grid.cell), (float)(11.0 * target),
                                (float*)ctx->flag_buf.p, (float2*)ctx->dens_buf.p);
             PCT_HIP(ctx, hipGetLastError());
         }
+        if (ctx->levels_fuse_fit) PCT_TRY(pct_launch_fit_pass(ctx, owned));       // before the next pass reorders the cloud
         const double t2 = debug ? tick() : 0;
         const int64_t total = owned * k;
         hipLaunchKernelGGL(k_merge_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
@@ -245,7 +245,13 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
                            (float2*)ctx->dens_buf.p, ctx->n);
         PCT_HIP(ctx, hipGetLastError());
         // pass 0: every owned query, cells sized as for a plain sweep
+        ctx->lvl_src_valid = false;
         PCT_TRY(run_pass(nq, false));
+        // the later passes bin the points in THIS pass's cell order (lanes of a wave then share their cells: the
+        // histogram's atomics combine, k_hist_agg) and reuse its box
+        PCT_TRY(pct_reserve(ctx, &ctx->lvl_src, (size_t)ctx->n * sizeof(float4)));
+        PCT_HIP(ctx, hipMemcpyAsync(ctx->lvl_src.p, ctx->sorted4.p, (size_t)ctx->n * sizeof(float4), hipMemcpyDeviceToDevice, ctx->stream));
+        ctx->lvl_src_valid = ctx->n_grid == ctx->n;
         const float log_edge0 = (float)log2(ctx->grid.cell);
         BandStats* d_st = (BandStats*)ctx->stage_d.p;
         int* d_box = (int*)((char*)ctx->stage_d.p + sizeof(BandStats));        // 6 ints + count
@@ -315,6 +321,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
     ctx->level_edge = 0;
     ctx->level_box_valid = false;
     ctx->level_mode = false;
+    ctx->lvl_src_valid = false;
     if (st != PCT_OK) return st;
     // the merged table takes the place of the pass table: public space, as after the exhaustive sweep
     swap_buf(ctx->nbr_pos, ctx->pub_pos);
@@ -323,5 +330,6 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
     ctx->nbr_pitch = pitch;
     ctx->knn_sorted_space = false;
     ctx->tm.levels = passes;
+    ctx->levels_fitted = ctx->levels_fuse_fit;
     return PCT_OK;
 }

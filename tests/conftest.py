@@ -11,6 +11,10 @@ for p in (ROOT, os.path.join(ROOT, "oracle")):
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# glibc writes its fatal diagnostics ("free(): invalid pointer", "malloc(): corrupted top size", stack smashing ...) to
+# the controlling TERMINAL unless told otherwise -- on a GPU box they vanish and all a log shows is "Aborted".
+os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
