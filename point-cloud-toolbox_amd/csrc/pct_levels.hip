@@ -19,6 +19,10 @@
 
 namespace {
 
+#ifndef PCT_LEVEL_STEP_MAX
+#define PCT_LEVEL_STEP_MAX 3.f
+#endif
+constexpr float kStepMax = PCT_LEVEL_STEP_MAX;   // largest jump (octaves of cell edge) taken on the population estimate alone
 constexpr float kWantExact = 1.0e30f;          // wanted-edge value of a query only the exact sweep can answer
 constexpr int kBins = 160;                      // histogram of wanted log2 edges, quarter octaves
 constexpr float kBinLo = -20.f;                 // relative to the first pass's log2 edge
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void k_classify(const int* __restrict__ row_do
                 // population ~ edge^2 on a surface, ~ edge^3 in a volume: the square root over-shoots in a volume,
                 // the bracket then takes over
                 const float step = 0.5f * log2f(fmaxf(target / fmaxf(pop, 0.5f), 1e-6f));
-                w = why == 1 ? log_edge + fminf(fmaxf(step, 0.75f), 3.f) : log_edge + fmaxf(fminf(step, -0.75f), -3.f);
+                w = why == 1 ? log_edge + fminf(fmaxf(step, 0.75f), kStepMax) : log_edge + fmaxf(fminf(step, -0.75f), -kStepMax);
             }
         }
         bracket[pub] = b;
