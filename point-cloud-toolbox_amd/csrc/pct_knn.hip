@@ -1785,7 +1785,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         const bool e = eps > 0, pre = !ctx->has_f64 && f32_ok, r1 = k + 1 <= pct_fast_r1_max();
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        static const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;          // tuning aid
+        const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;                 // tuning aid (read per call: tests flip it)
 #define PCT_FAST_PAIR(R_, E_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \

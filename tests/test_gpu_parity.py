@@ -728,6 +728,41 @@ def test_reference_generator_lattice_1m(gpu, golden, shape):
     h.close()
 
 
+@pytest.mark.parametrize("variant", ["k100_two_registers", "float64_cloud", "eps_ball", "k30_single_query_path"])
+def test_lattice_variants_stay_on_the_fast_sweep_and_equal_the_exhaustive_one(gpu, variant, monkeypatch):
+    """order_equal_keys in every instantiation of the sweep (two list registers, float64 queries, eps bound, the
+    unpaired loop) on the reference's lattice torus, 300 x 300: bit-identical to the exhaustive sweep, curvatures
+    included, and almost nothing left to the exact kernel."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_grid(300)
+    k, eps = 50, 0.0
+    if variant == "k100_two_registers":
+        k = 100
+    elif variant == "float64_cloud":
+        pts = gpu["shapes"].torus_grid(300, dtype=np.float64)
+    elif variant == "eps_ball":
+        eps = 0.045
+    else:
+        k = 30
+        monkeypatch.setenv("PCT_NO_PAIR", "1")       # the one-query-per-trip loop (a tuning aid the library reads per call)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.set_stats(True)
+    h.curvature(k, eps, capi.KNN_GRID)
+    redone = h.timings()["redone_queries"]
+    ig, dg, cg = h.get_neighbors(0, len(pts), want_count=True)
+    cf, K, H, _ = h.get_fit(0, len(pts))
+    h.curvature(k, eps, capi.KNN_BRUTE)
+    ib, db, cb = h.get_neighbors(0, len(pts), want_count=True)
+    cfb, Kb, Hb, _ = h.get_fit(0, len(pts))
+    h.close()
+    assert np.array_equal(ig, ib) and np.array_equal(dg, db) and np.array_equal(cg, cb)
+    assert np.array_equal(cf, cfb, equal_nan=True) and np.array_equal(K, Kb, equal_nan=True) and np.array_equal(H, Hb, equal_nan=True)
+    assert redone < 0.05 * len(pts), f"{redone} of {len(pts)} queries left the fast sweep"
+    if eps:
+        assert cg.min() < k <= cg.max()              # the eps bound binds for some rows and not for others
+
+
 def test_sample_scan_egg_carton_full_lattice(gpu, golden):
     """sample_scans/egg_carton.txt, all 99 856 points (316 x 316 lattice) as the file constructor leaves them."""
     g = golden("g9_eggcarton_file_k30_sample.npz")

@@ -1,6 +1,6 @@
 """Stage times and redo fraction on the reference's own lattice inputs next to the random torus (developer tool).
 
-    python tools/lattice_probe.py [n_side] [k]
+    python tools/lattice_probe.py [n_side] [k] [substring of the cloud's name]
 """
 import os, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -20,8 +20,11 @@ clouds = {
 eggf = os.path.join(ROOT, "tests", "golden", "g9_eggcarton_file_k30_sample.npz")
 if os.path.exists(eggf):
     clouds["egg_carton.txt (file ctor)"] = np.load(eggf)["points"]
+only = sys.argv[3] if len(sys.argv) > 3 else None
 out = {}
 for name, p in clouds.items():
+    if only and only not in name:
+        continue
     kk = 30 if "txt" in name else k
     p = np.ascontiguousarray(p, dtype=np.float32)
     h = _capi.Handle(0)

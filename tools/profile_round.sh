@@ -6,22 +6,38 @@ O=gpurun_out/prof_${1:-x}
 rm -rf $O; mkdir -p $O
 python bench.py > $O/bench.json 2> $O/bench.err
 echo bench done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras > $O/stats.log 2>&1
+B="python3 bench.py --no-cpu-baseline --no-extras"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- $B --steps 5 --warmup 2 > $O/stats.log 2>&1
 echo stats done
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B --steps 2 --warmup 1 > $O/fetch.log 2>&1
 echo fetch done
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/write.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write -- $B --steps 2 --warmup 1 > $O/write.log 2>&1
 echo write done
-rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $O/sq1 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/sq1.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA --output-format csv -d $O/sq1 -- $B --steps 2 --warmup 1 > $O/sq1.log 2>&1
 echo sq1 done
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $O/sq2.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- $B --steps 2 --warmup 1 > $O/sq2.log 2>&1
 echo sq2 done
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -- python3 tools/lattice_probe.py > $O/lattice.log 2>&1
+# the reference's own lattice torus (utils.py:883), same step
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -- python3 tools/lattice_probe.py 1000 50 "torus grid" > $O/lattice.log 2>&1
 echo lattice done
+find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 find $O/lat -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/lattice_kernel_stats.csv
 python tools/pmc_summary.py $O/sq1 $O/sq2 > $O/sq.json
 python tools/pmc_summary.py $O/fetch $O/write > $O/traffic_raw.json
-find $O -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+python - $O <<'PY'
+import json, sys
+o = sys.argv[1]
+d = json.load(open(o + "/traffic_raw.json"))
+f, w = d["k_knn_fast"]["FETCH_SIZE"], d["k_knn_fast"]["WRITE_SIZE"]
+json.dump({"kernel": "k_knn_fast<1,false,true,true,false>",
+           "config": "torus 1M seed 1234 k=50, bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
+           "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
+           "correction": "gfx950: FETCH_SIZE reports half of the bytes of 16 B/lane reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
+           "hbm_bytes_per_launch": (2 * f + w) * 1024,
+           "other_kernels_KB": {k: v for k, v in d.items() if k != "k_knn_fast"},
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/profile_round.sh)"},
+          open(o + "/knn_traffic.json", "w"), indent=1)
+PY
 # keep only the summaries (the raw traces are large)
 rm -rf $O/stats $O/fetch $O/write $O/sq1 $O/sq2 $O/lat
 ls -la $O
