@@ -208,17 +208,16 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     if (k < 1 || k > 127) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,127]", k);
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
     if (!(eps >= 0) || isinf(eps)) eps = 0;
+    const bool auto_req = algo == PCT_KNN_AUTO;
     if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
     if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS)
         return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
-    // (ctx->uneven records that the last plain grid sweep left > 5 % of the queries to the exact kernel; the chained
-    // sweep is opt-in all the same: it wins on extreme density ranges only)
     ctx->knn_valid = ctx->fit_valid = false;
     ctx->k = k;
     ctx->eps = eps;
     PCT_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->tm.levels = 0;
-    if (algo == PCT_KNN_GRID_LEVELS) {
+    const auto run_levels = [&]() -> int {
         PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->levels_fuse_fit = fuse_fit;
         const int lst = pct_knn_levels(ctx, k, eps);
@@ -230,11 +229,31 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         ctx->knn_valid = true;
         ctx->last_levels = true;
         return PCT_OK;
-    }
+    };
+    if (algo == PCT_KNN_GRID_LEVELS) return run_levels();
     ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
     if (grid) {
         PCT_TRY(pct_build_grid(ctx, k, eps));
+        // PCT_KNN_AUTO on a whole cloud: is one cell size enough?  A point of a cloud of even density shares its cell
+        // with about as many points as a non-empty cell holds on average; where the density spans decades the first
+        // figure (size-biased) runs away from the second.  Only then the work items are counted: the share of queries
+        // whose 27-cell stencil overflows the staging area or cannot hold k+1 points -- they would all go through the
+        // wave-per-query exact sweep -- and how many stencil cells the others find non-empty (about 9-13 on a surface,
+        // up to 27 in a volume, where the chain of cell lists does not pay).
+        if (auto_req && algo == PCT_KNN_GRID && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n >= 65536 && ctx->n < ((int64_t)1 << 29) &&
+            ctx->nonempty_cells > 0 && !getenv("PCT_NO_AUTO_LEVELS")) {
+            const double skew = ctx->tm.occupancy * (double)ctx->nonempty_cells / (double)ctx->n;
+            if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] occupancy %.1f, %lld non-empty cells, skew %.2f\n", ctx->tm.occupancy, (long long)ctx->nonempty_cells, skew);
+            if (skew > 1.5) {
+                unsigned long long c[4];
+                PCT_TRY(pct_item_census(ctx, k, c));
+                const double q = (double)(c[0] ? c[0] : 1), fail = (double)(c[1] + c[2]) / q, fine = (double)c[0] - (double)(c[1] + c[2]);
+                const double cells = fine > 0 ? (double)c[3] / fine : 27.0;
+                if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
+                if (fail > 0.30 && fine > 0.02 * q && cells < 15.0) return run_levels();
+            }
+        }
     } else {
         float bbox[6];
         PCT_TRY(pct_pack_points(ctx, bbox));

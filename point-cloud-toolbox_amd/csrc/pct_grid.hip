@@ -411,13 +411,14 @@ __global__ __launch_bounds__(kBlock) void k_hist_agg(const float4* __restrict__ 
 constexpr int kScanItems = 8;                    // per thread
 constexpr int kScanTile = kBlock * kScanItems;   // 2048 cells per block
 
-__device__ __forceinline__ int4 add3(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, 0); }
+// (x, y, z are scanned; w just counts the non-empty cells along)
+__device__ __forceinline__ int4 add3(int4 a, int4 b) { return make_int4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 
 __device__ __forceinline__ int4 cell_counts(const int* __restrict__ own, const int* __restrict__ oth, int64_t c, int64_t ncell, int items_q) {
     if (c >= ncell) return make_int4(0, 0, 0, 0);
     const int o = own[c];
     const int t = o + (oth ? oth[c] : 0);
-    return make_int4(t, (o + items_q - 1) / items_q, o, 0);
+    return make_int4(t, (o + items_q - 1) / items_q, o, t > 0 ? 1 : 0);
 }
 
 // first pass: per-tile sums; also accumulates sum_c owned_c * count_c (= sum over the owned points of the
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ ow
         sq += (unsigned long long)x.z * (unsigned)x.x;       // owned points x population of their cell
     }
     for (int o = 32; o > 0; o >>= 1) {
-        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o);
+        v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
         sq += __shfl_xor(sq, o);
     }
     if ((threadIdx.x & 63) == 0) {
@@ -997,6 +998,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                         "smallest usable cell edge %.3g (%lld cells); thin it out or split it into compact pieces",
                         m_last, g.cell, (long long)g.ncell);
     ctx->n_items = tot.y;
+    ctx->nonempty_cells = tot.w;
     ctx->n_occ = tot.y;
     ctx->tm.occupied_cells = tot.y;
     ctx->grid_valid = true;

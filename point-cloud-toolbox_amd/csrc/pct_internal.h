@@ -100,6 +100,7 @@ struct pct_ctx {
     pct_buf occ;        // int2 (n_items) work items {cell id, chunk of items_q queries}
     pct_buf redo;       // int32 (n) queries the fast sweep handed to the exact sweep
     int64_t n_items = 0;
+    int64_t nonempty_cells = 0;    // cells of the current cell list that hold at least one point
     int32_t items_q = 12;
     pct_buf sorted4;    // float4 (n) cell-sorted, w = public index bits
     pct_buf sorted4d;   // double4 (n) cell-sorted native coords (has_f64)
@@ -192,6 +193,10 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps);
 // neighbour sweeps (pct_knn.hip)
 int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, int phase = 0);
 int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
+// census of the work items of the cell list in place: out4 = {queries, queries whose stencil overflows the staging
+// area, queries whose stencil holds fewer than 2.5 (k+1) points (too few to vouch for k+1 within one cell edge), sum over the other queries of the non-empty cells in their
+// 27-cell stencil} -- what decides between the plain and the density-adaptive sweep before anything is swept
+int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]);
 int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps);     // pct_levels.hip
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);

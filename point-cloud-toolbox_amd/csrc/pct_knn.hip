@@ -34,6 +34,10 @@ constexpr int kWavesPerBlock = 4;
 #define PCT_STAGE_CAP 512
 #endif
 constexpr int kStageCap = PCT_STAGE_CAP;   // LDS-staged stencil candidates per wave and per 64 list slots (12 B each, SoA)
+#ifndef PCT_STAGE_CAP2
+#define PCT_STAGE_CAP2 768
+#endif
+constexpr int PCT_STAGE_CAP2_HOST = PCT_STAGE_CAP2;
 
 struct KnnArgs {
     const float4* pts;        // candidate records {x,y,z,public index}; cell-sorted (grid) or public order (brute)
@@ -1712,6 +1716,46 @@ __global__ __launch_bounds__(64) void k_selftest(int* fails) {
     if (bad) atomicAdd(fails, bad);
 }
 
+// One thread per work item: population and non-empty cells of its 27-cell stencil (pct_item_census).
+__global__ __launch_bounds__(256) void k_item_census(const int2* __restrict__ items, int64_t n_items, int items_q,
+                                                     const int* __restrict__ cs, const int* __restrict__ cell_own, pct_grid g, int k,
+                                                     int cap, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sh[4][4];
+    unsigned long long v[4] = {0, 0, 0, 0};
+    for (int64_t it = (int64_t)blockIdx.x * 256 + threadIdx.x; it < n_items; it += (int64_t)gridDim.x * 256) {
+        const int2 e = items[it];
+        const int cell = e.x;
+        const int cx = cell % g.nx, cy = (cell / g.nx) % g.ny, cz = cell / (g.nx * g.ny);
+        const int nq = min(items_q, cell_own[cell] - e.y * items_q);
+        int m = 0, occupied = 0;
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int z = cz + dz, y = cy + dy;
+                if (z < 0 || z >= g.nz || y < 0 || y >= g.ny) continue;
+                const int row = (z * g.ny + y) * g.nx;
+                int prev = cs[row + max(cx - 1, 0)];
+                for (int x = max(cx - 1, 0); x <= min(cx + 1, g.nx - 1); ++x) {
+                    const int next = cs[row + x + 1];
+                    occupied += next > prev;
+                    m += next - prev;
+                    prev = next;
+                }
+            }
+        v[0] += (unsigned)nq;
+        // the stencil vouches for about one cell edge around the query: on a surface that disc holds ~pi/9 of the
+        // stencil's population, so a stencil below ~2.5 (k+1) points will mostly fail the proof ("short")
+        if (m > cap) v[1] += (unsigned)nq;
+        else if (2 * m < 5 * (k + 1)) v[2] += (unsigned)nq;
+        else v[3] += (unsigned long long)nq * (unsigned)occupied;
+    }
+    for (int j = 0; j < 4; ++j) {
+        for (int o = 32; o > 0; o >>= 1) v[j] += __shfl_xor(v[j], o);
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6][j] = v[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) atomicAdd(&out[threadIdx.x], sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
 KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     KnnArgs a = {};
     a.pts = (const float4*)(grid ? ctx->sorted4.p : ctx->pts4.p);
@@ -1826,6 +1870,22 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         PCT_HIP(ctx, hipGetLastError());
     }
     ctx->knn_sorted_space = true;
+    return PCT_OK;
+}
+
+int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]) {
+    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    const int cap = k + 1 <= pct_fast_r1_max() ? kStageCap : PCT_STAGE_CAP2_HOST;
+    const int blocks = (int)((ctx->n_items + 255) / 256 < 1024 ? (ctx->n_items + 255) / 256 : 1024);
+    if (blocks > 0) {
+        hipLaunchKernelGGL(k_item_census, dim3(blocks), dim3(256), 0, ctx->stream, (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q,
+                           (const int*)ctx->cell_cnt.p, (const int*)ctx->cell_own.p, ctx->grid, k, cap, (unsigned long long*)ctx->counters.p);
+        PCT_HIP(ctx, hipGetLastError());
+    }
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 2112, ctx->counters.p, 32, hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out4, ctx->pin + 2112, 32);
     return PCT_OK;
 }
 

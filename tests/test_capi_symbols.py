@@ -65,3 +65,17 @@ def test_product_never_imports_the_oracle():
             src = open(os.path.join(pkg, fn)).read()
             assert "pct_oracle" not in src and "oracle" not in src.replace("the oracle", ""), fn
             assert "cKDTree" not in src, fn
+
+
+def test_product_runs_without_pytorch():
+    """north_star: no PyTorch on the path -- the multi-GPU exchange is RCCL behind the C ABI (pct_comm_*); torchrun may
+    start the processes, nothing imports torch."""
+    pkg = os.path.join(ROOT, "point-cloud-toolbox_amd")
+    for path in [os.path.join(pkg, f) for f in os.listdir(pkg) if f.endswith(".py")] + [os.path.join(ROOT, "bench.py"),
+                                                                                      os.path.join(ROOT, "pointCloudToolbox.py")]:
+        src = open(path).read()
+        assert not re.search(r"^\s*(import torch|from torch)", src, flags=re.M), path
+    comm = open(os.path.join(pkg, "csrc", "pct_comm.hip")).read()
+    for sym in ("ncclCommInitRank", "ncclAllGather", "ncclAllReduce", "ncclGetUniqueId"):
+        assert sym in comm
+    assert "pct_comm_allgather_f32" in declared_symbols()

@@ -192,6 +192,33 @@ def test_staticmethods_of_the_class(gpu, golden):
         assert np.allclose(cf, g2["coefs"][i], rtol=1e-5, atol=1e-6 * np.abs(g2["coefs"][i]).max())
 
 
+def test_batched_plane_rotate_and_quadric_entries(gpu, golden):
+    """pct_plane_rotate / pct_fit_quadric with a whole block of neighbourhoods per call (what a caller with many
+    neighbourhoods would do instead of the reference's per-point loop), float32 and float64 input."""
+    g = golden("g2_torus4k_k50.npz")
+    P, idx = g["points"], g["idx"]
+    rows = np.arange(0, 4000, 13)
+    h = gpu["capi"].Handle(0)
+    for dtype in (np.float32, np.float64):
+        block = (P[idx[rows]] - P[rows][:, None, :]).astype(dtype)              # (batch, 50, 3) centred neighbourhoods
+        rot = h.plane_rotate(block)
+        assert rot.shape == block.shape and rot.dtype == np.float64
+        for b in (0, 7, len(rows) - 1):
+            assert np.allclose(rot[b], oracle.plane_align(block[b]), rtol=0, atol=1e-13)
+        co = h.fit_quadric(rot.astype(np.float32))
+        assert co.shape == (len(rows), 6) and co.dtype == np.float32
+        if dtype == np.float32:
+            assert (co == g["coefs"][rows]).all(1).mean() > 0.95
+        assert np.allclose(co, g["coefs"][rows], rtol=1e-5, atol=1e-6 * np.abs(g["coefs"][rows]).max())
+    with pytest.raises(ValueError, match="Non-finite values in input points"):
+        bad = block.copy()
+        bad[3, 4, 1] = np.nan
+        h.plane_rotate(bad)
+    with pytest.raises(ValueError):
+        h.plane_rotate(block[:, :1])                                           # one point has no covariance
+    h.close()
+
+
 @pytest.mark.parametrize("tag", ["plane_1to20", "cyl_1to20", "wavy_1to20", "wavy_1to4", "wavy_1to4_jitter"])
 def test_scan_line_clouds_against_the_reference(gpu, golden, tag):
     """G10: clouds sampled densely along scan lines and sparsely across (0.005 x 0.1 / 0.02, k = 30: every
@@ -967,6 +994,33 @@ def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind):
         h.knn(k, eps=eps, algo=capi.KNN_GRID_LEVELS)
         i2, d2, c2 = h.get_neighbors(lo, hi, want_count=True)
         assert np.array_equal(i2, ib[lo:hi]) and np.array_equal(d2, db[lo:hi]) and np.array_equal(c2, cb[lo:hi])
+        h.close()
+
+
+def test_auto_takes_the_chain_of_cell_lists_only_where_it_pays(gpu):
+    """PCT_KNN_AUTO: a scan whose density falls off like 1/r^2 (one terrestrial laser station) goes through the
+    density-adaptive sweep, an even surface and a volume do not -- and whatever is chosen, the values are the same."""
+    capi = gpu["capi"]
+    rng = np.random.default_rng(8)
+    n = 400_000
+    r, a = 0.01 * 100 ** rng.uniform(0, 1, n), rng.uniform(0, 2 * np.pi, n)
+    lidar = np.stack([r * np.cos(a), r * np.sin(a), 0.05 * np.sin(r * np.cos(a)) * np.cos(r * np.sin(a))], 1).astype(np.float32)
+    clouds = {"lidar": lidar, "torus": gpu["shapes"].torus_random(n, seed=4), "blob": rng.normal(size=(n, 3)).astype(np.float32)}
+    for name, pts in clouds.items():
+        h = capi.Handle(0)
+        h.set_points(pts)
+        h.curvature(40, 0.0, capi.KNN_AUTO)
+        levels = h.timings()["levels"]
+        assert (levels > 0) == (name == "lidar"), (name, levels)
+        rows = np.arange(0, n, 41)
+        ia, da, _ = h.get_neighbor_rows(rows)
+        _, Ka, Ha, _ = h.get_fit(0, n, coefs=False, H2=False)
+        h.curvature(40, 0.0, capi.KNN_GRID)
+        assert h.timings()["levels"] == 0
+        ib, db, _ = h.get_neighbor_rows(rows)
+        _, Kb, Hb, _ = h.get_fit(0, n, coefs=False, H2=False)
+        assert np.array_equal(ia, ib) and np.array_equal(da, db)
+        assert np.array_equal(Ka, Kb, equal_nan=True) and np.array_equal(Ha, Hb, equal_nan=True)
         h.close()
 
 

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 import pct_oracle as oracle
+import pointCloudToolbox  # noqa: F401  (registers point_cloud_toolbox_amd)
 
 
 DS_CASES = ["f64", "f32", "lattice_f32", "lattice_f32_v01", "tuples"]
@@ -52,6 +53,16 @@ def test_gpu_estimate_curvature_default_follows_the_code_as_written(gpu, golden,
     assert np.abs(got - ref).max() < (1e-6 if ref.dtype == np.float32 else 1e-14)
     with pytest.raises(ValueError):
         estimate_curvature(g[f"ec_{tag}_in"][:4])                    # k = 5 > 4 points: sklearn refuses too
+
+
+def test_estimate_curvature_default_needs_no_device(golden):
+    """The code as written returns round-off around an exactly-zero eigenvalue: the default answer is that zero, in the
+    dtype NumPy would give, for any cloud the reference's function accepts."""
+    from point_cloud_toolbox_amd.prep import estimate_curvature
+    g = golden("g11_prep.npz")
+    for tag in ("torus2k_f32", "torus2k_f64", "torus150_f32"):
+        out = estimate_curvature(g[f"ec_{tag}_in"])
+        assert out.dtype == g[f"ec_{tag}_out"].dtype and out.shape == g[f"ec_{tag}_out"].shape and not out.any()
 
 
 def test_oracle_downsample_semantics():

@@ -42,6 +42,13 @@ for name, p in clouds.items():
         t = h.timings()
         if lv is None or t["total_ms"] < lv["total_ms"]:
             lv = t
+    au = None
+    for _ in range(3):
+        h.curvature(50, 0.0, _capi.KNN_AUTO)
+        t = h.timings()
+        if au is None or t["total_ms"] < au["total_ms"]:
+            au = t
+    print(f"{name:22s} AUTO   total {au['total_ms']:8.3f} ms (levels {au['levels']})")
     print(f"{name:22s} LEVELS total {lv['total_ms']:8.3f} ms knn {lv['knn_ms']:.3f} fit {lv['fit_ms']:.3f} levels {lv['levels']}")
     print(f"{name:22s} total {best['total_ms']:8.3f} ms  grid {best['grid_ms']:.3f} knn {best['knn_ms']:.3f} (fast {best['knn_fast_ms']:.3f}) fit {best['fit_ms']:.3f} | "
           f"iters {best['grid_iters']} m {best['occupancy']:.1f} cells {best['cells']} redo {s['redone_queries']} ovf-items {s['lds_overflows']} ring>1 {s['ring_fallbacks']}", flush=True)
