@@ -18,7 +18,7 @@ echo sq1 done
 rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_ACTIVE_INST_ANY --output-format csv -d $O/sq2 -- $B --steps 2 --warmup 1 > $O/sq2.log 2>&1
 echo sq2 done
 # the reference's own lattice torus (utils.py:883), same step
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -- python3 tools/lattice_probe.py 1000 50 "torus grid" > $O/lattice.log 2>&1
+PCT_PROBE_NO_STATS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -- python3 tools/lattice_probe.py 1000 50 "torus grid" > $O/lattice.log 2>&1
 echo lattice done
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 find $O/lat -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/lattice_kernel_stats.csv
