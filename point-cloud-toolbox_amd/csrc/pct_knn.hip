@@ -478,10 +478,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
 //     key << SLOT_BITS | payload
 // payload = LDS slot of a staged stencil candidate (or, on the pre-selection path, the candidate's place in the
 // compacted list of survivors, from which the slot is looked up afterwards); key = floor(d2 * scale) with the
-// exact fp64 squared distance d2 and scale = 2^KEY_BITS / (12.1 cell^2), the largest squared distance the
-// 27-cell stencil can hold.  The quantisation is a monotone map of the exact value, so wherever two keys differ
-// the order is the exact order.  Every situation in which a key collision could influence the k+1 smallest
-// (equal neighbours among the first k+2 of the sorted selection, a saturated key), every query whose answer is
+// exact fp64 squared distance d2 and scale = 2^KEY_BITS / (2.3 cell^2), just above the largest squared distance the
+// 27-cell stencil can VOUCH for (beyond it keys saturate).  The quantisation is a monotone map of the exact value, so
+// wherever two keys differ the order is the exact order.  Equal keys among the first k+2 of the sorted selection are
+// put in the exact order in place (order_equal_keys); a saturated (k+1)-th key, every query whose answer is
 // not guaranteed to lie inside the stencil or inside what the float32 pre-selection kept, and whole items whose
 // stencil does not fit the LDS staging area are appended to the redo list and done by k_knn_exact.  Unflagged
 // results are therefore bit-identical to the exact path: the stored distance is recomputed in fp64 from the
@@ -875,7 +875,14 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
     wave_lds_sync();
     const int k = a.k;
     const double eps2 = EPS ? a.eps2 : (double)INFINITY;
-    const double scale = (double)(1u << KEY_BITS) / (12.1 * g.cell * g.cell);
+    // Key range: the cube of 27 cells vouches for at most 1.5 cell edges around a query (min(gx + 1, 2 - gx) <= 1.5 per
+    // axis, guaranteed_r2), so no accepted list holds a squared distance beyond 2.25 cell^2: candidates farther out
+    // (the stencil reaches 12 cell^2) may share the saturated key -- if the (k+1)-th is among them the query was
+    // beyond the guarantee anyway.  (Until round 2 the range was the stencil's 12.1 cell^2: keys 5x coarser, equal
+    // keys 5x as frequent.  Queries at the rim of the grid, whose guarantee is unbounded on a side, can lose a
+    // provable answer to the saturation check: exact sweep.)
+    constexpr double kKeyRange = 2.3;
+    const double scale = (double)(1u << KEY_BITS) / (kKeyRange * g.cell * g.cell);
     const unsigned key_max = (1u << KEY_BITS) - 1u;
     // Per query, the largest key the stencil can vouch for: lane l evaluates query l once per item (the radius
     // guaranteed by the 27-cell cube depends on where the query sits inside its cell).  floor() keeps it conservative.
@@ -1389,7 +1396,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
             int cnt = total;
             if (total > LIST) {
                 unsigned lo = 0u, hi = key_max + 1u;          // count(lo) < k+1 ; count(hi) > LIST
-                unsigned t = t_prev ? t_prev : (unsigned)((double)(1u << KEY_BITS) / 12.1);   // first guess: one cell edge
+                unsigned t = t_prev ? t_prev : (unsigned)((double)(1u << KEY_BITS) / kKeyRange);   // first guess: one cell edge
                 const float target = 0.5f * (float)(k + 1 + LIST);
                 bool found = false;
 #pragma unroll 1
