@@ -745,6 +745,9 @@ static void set_dims(pct_grid* g, const float* bbox, double a) {
     g->cell = a;
     g->inv_cell = 1.0 / a;
     double ex = (double)bbox[3] - bbox[0], ey = (double)bbox[4] - bbox[1], ez = (double)bbox[5] - bbox[2];
+    if (!(ex >= 0)) ex = 0;          // an empty or non-finite box is one cell, not INT_MIN cells
+    if (!(ey >= 0)) ey = 0;
+    if (!(ez >= 0)) ez = 0;
     // counted in double first: an absurdly small edge (eps = 1e-30) must read as "far too many cells" for the caller's
     // budget loop, not overflow the int32 dimensions
     const double dx = floor(ex * g->inv_cell) + 1, dy = floor(ey * g->inv_cell) + 1, dz = floor(ez * g->inv_cell) + 1;
@@ -900,6 +903,9 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            src, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
+        if (getenv("PCT_GRID_DEBUG"))
+            fprintf(stderr, "[grid] pass %d: n %lld owned %lld edge %g dims %d x %d x %d = %lld cells (%d scan tiles), box [%g %g %g]-[%g %g %g]\n", it,
+                    (long long)n, (long long)n_owned, a, g.nx, g.ny, g.nz, (long long)g.ncell, nblk, bbox[0], bbox[1], bbox[2], bbox[3], bbox[4], bbox[5]);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
         unsigned long long* sq_part = (unsigned long long*)((int4*)ctx->scan_tmp.p + nblk + 1);
         PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));

@@ -108,8 +108,14 @@ __global__ __launch_bounds__(256) void k_band_hist(const float* __restrict__ wan
         if (w == w) {
             if (w >= 0.5f * kWantExact) atomicAdd(&sh[kBins], 1u);
             else {
-                const int bin = (int)floorf((w - log_edge0 - kBinLo) * 4.f);
-                atomicAdd(&sh[bin < 0 ? 0 : bin >= kBins ? kBins - 1 : bin], 1u);
+                // the bin whose float bounds -- the very expressions the host turns a window of bins into [lo, hi)
+                // with -- hold w: floor() of the scaled offset can land one bin off at a boundary, and a window
+                // that the histogram says holds 2313 queries then owned none (box [inf, -inf], a launch of no blocks)
+                int bin = (int)floorf((w - log_edge0 - kBinLo) * 4.f);
+                bin = bin < 0 ? 0 : bin >= kBins ? kBins - 1 : bin;
+                while (bin > 0 && w < log_edge0 + kBinLo + 0.25f * bin) --bin;
+                while (bin < kBins - 1 && w >= log_edge0 + kBinLo + 0.25f * (bin + 1)) ++bin;
+                atomicAdd(&sh[bin], 1u);
             }
         }
     }
@@ -300,6 +306,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
             ctx->own_lo = lo;
             ctx->own_hi = hi;
             ctx->own_count = (int64_t)(unsigned)hb[6];
+            if (ctx->own_count <= 0) break;            // (cannot happen while histogram and window agree; never build a cell list for nobody)
             ctx->level_edge = exp2((double)log_edge0 + kBinLo + 0.25 * (best + 2));        // centre of the window
             PCT_TRY(run_pass(ctx->own_count, false));
         }

@@ -19,7 +19,6 @@ Deliberate, documented differences (none changes a value):
 from __future__ import annotations
 
 import atexit
-import gc
 import threading
 
 import numpy as np
@@ -127,7 +126,6 @@ class PointCloud:
         points = _capi.load_text(self.file_path)           # np.loadtxt semantics, native multi-threaded parser
         self.points = points[:, 0:3].astype(np.float32)
         self.normals = points[:, 3:6].astype(np.float32)
-        gc.collect()
         self.points[:, 0] -= np.max(self.points[:, 0])
         self.points[:, 1] -= np.max(self.points[:, 1])
         if self.downsample:

@@ -1024,6 +1024,27 @@ def test_auto_takes_the_chain_of_cell_lists_only_where_it_pays(gpu):
         h.close()
 
 
+def test_chain_window_and_histogram_agree_at_a_bin_boundary(gpu):
+    """Found by tools/fuzz_gpu.py (seed 31, case 5827): a float64 cloud far from the origin, quantised by float32 into
+    piles of identical points -- every pending query of the chained sweep wanted exactly the edge of a histogram bin
+    boundary; floor() put them into a window that the [lo, hi) test then found empty, and a cell list was built for
+    nobody (grid of INT_MIN cells, launch of no blocks).  Bit-identical to the exhaustive sweep now."""
+    capi = gpu["capi"]
+    _, pts, n, k, kind, eps = _tool("fuzz_gpu").make_case(31, 5827)
+    assert (n, k, kind) == (36111, 25, 7) and pts.dtype == np.float64
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.curvature(k, eps, capi.KNN_BRUTE)
+    ib, db, _ = h.get_neighbors(0, n)
+    _, Kb, Hb, _ = h.get_fit(0, n, coefs=False, H2=False)
+    h.curvature(k, eps, capi.KNN_GRID_LEVELS)
+    ig, dg, _ = h.get_neighbors(0, n)
+    _, Kg, Hg, _ = h.get_fit(0, n, coefs=False, H2=False)
+    h.close()
+    assert np.array_equal(ib, ig) and np.array_equal(db, dg)
+    assert np.array_equal(Kb, Kg, equal_nan=True) and np.array_equal(Hb, Hg, equal_nan=True)
+
+
 def test_random_cross_check(gpu):
     """tools/fuzz_gpu.py for a fixed seed: random clouds (torus, Gaussian at random scale, lattice with ties, blobs of
     uneven density, shifted egg carton, a line with a far sub-line), random k, eps, dtype, shard -- plain grid sweep,
