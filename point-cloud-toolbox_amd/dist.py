@@ -123,7 +123,9 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
 
 # ------------------------------------------------------------------ exchange
 class RcclExchange:
-    """All-gather of device-resident float32 shards through the handle's RCCL communicator (``pct_comm_*``)."""
+    """All-gather of device-resident float32 shards through the handle's RCCL communicator (``pct_comm_*``).
+    (Multi-process RCCL on this platform needs ``HSA_ENABLE_IPC_MODE_LEGACY=0`` in the environment BEFORE the HIP
+    runtime starts -- the host driver supports dmabuf IPC only; ``bench.py`` sets it if the launcher did not.)"""
 
     def __init__(self, handle, rank, world, addr=None, port=None):
         from . import _capi
