@@ -183,6 +183,12 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip first-call / end-to-end / lattice / repeat measurements")
     args = ap.parse_args()
 
+    # ONE JSON line on stdout: whatever the libraries below print on it (RCCL 2.27 announces its version there at
+    # communicator creation, hipcc may talk during a rebuild) goes to stderr instead -- at the descriptor level.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -361,7 +367,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.config == "c3":
             out["cpu_baseline"] = cpu_baseline(local, k)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if exchange is not None:
         exchange.barrier()
     if sc is not None:
