@@ -96,3 +96,16 @@ def test_tree_wrapper_checks_its_arguments_before_touching_the_device(built):
         t.query(np.zeros(3), 0)
     with pytest.raises(ValueError):
         t.query(np.zeros(3), 2.5)
+
+
+def test_staticmethods_validate_before_touching_the_device(built):
+    """pct:273-274, 351-357: the reference's own checks and messages, raised by the host wrapper (no GPU needed)."""
+    PC = built["PointCloud"]
+    with pytest.raises(ValueError, match="Non-finite values in input points"):
+        PC.get_best_fit_plane_and_rotate(np.array([[0.0, 0, 0], [1, np.inf, 0], [0, 1, 0]]))
+    with pytest.raises(ValueError, match=r"Input points must have shape \(N, 3\)"):
+        PC.fit_quadratic_surface(np.zeros((4, 2)))
+    with pytest.raises(ValueError, match=r"Input points must have shape \(N, 3\)"):
+        PC.fit_quadratic_surface(np.zeros(3))
+    with pytest.raises(ValueError, match="Input contains non-finite values."):
+        PC.fit_quadratic_surface(np.array([[0.0, 0, 0], [1, np.nan, 0], [0, 1, 0]]))
