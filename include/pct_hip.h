@@ -36,7 +36,10 @@ enum pct_knn_algo {
     PCT_KNN_GRID = 2,         /* uniform cell list, LDS-staged 27-cell stencil          */
     PCT_KNN_GRID_EXACT = 3,   /* same cell list, every query through the exact sweep    */
     PCT_KNN_GRID_LEVELS = 4   /* chain of cell lists, each sized for the queries the previous
-                                 one could not answer (clouds of very uneven density)   */
+                                 one could not answer (clouds of very uneven density);
+                                 PCT_KNN_AUTO takes it by itself where a census of the work
+                                 items predicts that it pays (surface-like clouds whose
+                                 density spans decades)                                  */
 };
 
 /* Per-stage device times of the most recent call, hipEvent milliseconds. */

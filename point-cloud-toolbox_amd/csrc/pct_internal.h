@@ -109,7 +109,7 @@ struct pct_ctx {
     pct_buf red;        // small reduction scratch
     // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
     // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
-    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd
+    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd  [2112,2144) work-item census of PCT_KNN_AUTO
     unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;
