@@ -1045,6 +1045,32 @@ def test_chain_window_and_histogram_agree_at_a_bin_boundary(gpu):
     assert np.array_equal(Kb, Kg, equal_nan=True) and np.array_equal(Hb, Hg, equal_nan=True)
 
 
+def test_pointcloud_flow_on_a_lidar_like_scan(gpu):
+    """The class surface on a cloud whose density falls off like 1/r^2 (default algorithm: the chain of cell lists is
+    taken by itself): planting, lazy neighbour download, neighbour study, separate fit, curvatures -- against the
+    oracle on sampled rows."""
+    rng = np.random.default_rng(18)
+    n = 200_000
+    r, a = 0.02 * 50 ** rng.uniform(0, 1, n), rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(a), r * np.sin(a)
+    pts = np.stack([x, y, 0.1 * np.sin(2 * x) * np.cos(2 * y)], 1).astype(np.float32)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((n, 0)))
+    pc.plant_kdtree(100)
+    assert pc.last_timings["levels"] > 0
+    np.random.seed(3)
+    conv = pc.explicit_quadratic_neighbor_study(sample_size=30)
+    np.random.seed(3)
+    ref_conv, _ = oracle.neighbor_study(pts, np.random.randint(0, n, 30))
+    assert conv == ref_conv
+    pc.plant_kdtree(40)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    rows = np.sort(rng.choice(n, 1500, replace=False))
+    ref = oracle.pipeline_batched(pts, 40, rows=rows)
+    assert np.array_equal(pc.neighbor_indices[rows], ref["idx"]) and np.array_equal(pc.dists[rows], ref["dists"])
+    assert_curvature(K[rows], H[rows], ref["K"], ref["H"])
+    pc.close()
+
+
 def test_random_cross_check(gpu):
     """tools/fuzz_gpu.py for a fixed seed: random clouds (torus, Gaussian at random scale, lattice with ties, blobs of
     uneven density, shifted egg carton, a line with a far sub-line), random k, eps, dtype, shard -- plain grid sweep,
