@@ -35,11 +35,15 @@ enum pct_knn_algo {
     PCT_KNN_BRUTE = 1,        /* exhaustive wave-per-query sweep                        */
     PCT_KNN_GRID = 2,         /* uniform cell list, LDS-staged 27-cell stencil          */
     PCT_KNN_GRID_EXACT = 3,   /* same cell list, every query through the exact sweep    */
-    PCT_KNN_GRID_LEVELS = 4   /* chain of cell lists, each sized for the queries the previous
+    PCT_KNN_GRID_LEVELS = 4,  /* chain of cell lists, each sized for the queries the previous
                                  one could not answer (clouds of very uneven density);
                                  PCT_KNN_AUTO takes it by itself where a census of the work
                                  items predicts that it pays (surface-like clouds whose
                                  density spans decades)                                  */
+    PCT_KNN_TREE = 5          /* hierarchical cell list: the cloud in Morton order, every
+                                 query served at the octree level that suits its density;
+                                 what it cannot prove goes down the chain above (whole
+                                 float32 clouds; otherwise the same as GRID_LEVELS)      */
 };
 
 /* Per-stage device times of the most recent call, hipEvent milliseconds. */

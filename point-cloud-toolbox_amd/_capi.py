@@ -23,7 +23,7 @@ PCT_ERR_K_TOO_LARGE = 5
 PCT_ERR_OOM = 6
 PCT_ERR_NO_NEIGHBORS = 7
 
-KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT, KNN_GRID_LEVELS = 0, 1, 2, 3, 4
+KNN_AUTO, KNN_BRUTE, KNN_GRID, KNN_GRID_EXACT, KNN_GRID_LEVELS, KNN_TREE = 0, 1, 2, 3, 4, 5
 
 
 class Timings(C.Structure):

@@ -93,7 +93,8 @@ void pct_destroy(pct_ctx* ctx) {
     pct_buf* all[] = {&ctx->xyz, &ctx->pts4, &ctx->pts4d, &ctx->cell_of, &ctx->cell_cnt, &ctx->cell_fill,
                       &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
-                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4, &ctx->fit_flag, &ctx->lvl_src};
+                      &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4, &ctx->fit_flag, &ctx->lvl_src,
+                      &ctx->tree_codes, &ctx->tree_vals, &ctx->tree_lvl, &ctx->tree_head, &ctx->tree_marks, &ctx->tree_seg, &ctx->tree_runs, &ctx->tree_range, &ctx->tree_tmp};
     for (pct_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
@@ -210,7 +211,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     if (!(eps >= 0) || isinf(eps)) eps = 0;
     const bool auto_req = algo == PCT_KNN_AUTO;
     if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
-    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS)
+    if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS && algo != PCT_KNN_TREE)
         return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
     ctx->knn_valid = ctx->fit_valid = false;
     ctx->k = k;
@@ -230,6 +231,19 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         ctx->last_levels = true;
         return PCT_OK;
     };
+    // the hierarchical cell list takes whole float32 clouds; anything else goes down the chain of cell lists
+    const bool tree_ok = !ctx->has_f64 && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n < ((int64_t)1 << 26);
+    const auto run_tree = [&]() -> int {
+        ctx->last_levels = false;
+        PCT_TRY(pct_build_tree(ctx, k, eps));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        PCT_TRY(pct_launch_knn_tree(ctx, k, eps));
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+        ctx->tm.knn_launches = 1;
+        ctx->knn_valid = true;
+        return PCT_OK;
+    };
+    if (algo == PCT_KNN_TREE) return tree_ok ? run_tree() : run_levels();
     if (algo == PCT_KNN_GRID_LEVELS) return run_levels();
     ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
@@ -281,6 +295,9 @@ static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
     ctx->tm.lds_overflows = (int64_t)c[1];
     ctx->tm.flushes = (int64_t)c[2];
     ctx->tm.candidate_steps = (int64_t)c[3];
+    if (getenv("PCT_TREE_DEBUG") && ctx->collect_stats)
+        fprintf(stderr, "[tree] redone %llu, up-levelled %llu, candidate steps %llu, costliest exact query: %llu steps (row %llu)\n", c[4], c[0], c[3],
+                c[6] >> 32, c[6] & 0xffffffffull);
     ctx->tm.redone_queries = (int64_t)c[4];
     ctx->tm.grid_ms = ev_ms(ctx, 2, 3);
     ctx->tm.knn_ms = ev_ms(ctx, 3, 4);

@@ -72,6 +72,15 @@ struct pct_ctx {
     pct_buf lvl_src;                // float4 (n): the points in the cell order of the first pass (input of the later passes' builds)
     bool lvl_src_valid = false;
     float lvl_bbox[6] = {0, 0, 0, 0, 0, 0};
+    // hierarchical cell list (pct_tree.hip)
+    int tree_bits = 0;
+    int64_t tree_segs = 0;
+    pct_buf tree_codes, tree_vals;  // u64 / u32 (2 n): Morton codes and public positions, unsorted | sorted
+    pct_buf tree_lvl;               // u8 (n): octree level every point is served at
+    pct_buf tree_head, tree_marks;  // segment / item marks and their scans
+    pct_buf tree_seg, tree_runs;    // int4 per segment {level, cx, cy, cz}; int2 x 27 per segment {first position, points}
+    pct_buf tree_range;             // int2 per segment {first position, points} + int per segment: stencil population + device totals
+    pct_buf tree_tmp;
     pct_buf row_done;               // int32 (rows of the pass)
     pct_buf redo_m;                 // int32, parallel to redo: stencil population of the row's item
     pct_buf flag_buf;               // float (n): wanted log2 cell edge of every point still unanswered (NaN = answered)
@@ -109,7 +118,7 @@ struct pct_ctx {
     pct_buf red;        // small reduction scratch
     // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
     // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
-    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd  [2112,2144) work-item census of PCT_KNN_AUTO
+    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd  [2112,2144) work-item census of PCT_KNN_AUTO  [2176,2216) totals of the tree build
     unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;
@@ -172,6 +181,42 @@ inline double pct_default_factor(int k) {
 }
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);
 
+// Morton codes of the hierarchical cell list: 21 bits per axis, x in bit 0 of every triple
+__host__ __device__ inline unsigned long long pct_spread3(unsigned v) {         // bit i -> bit 3 i
+    unsigned long long x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__host__ __device__ inline unsigned pct_compact3(unsigned long long x) {        // bit 3 i -> bit i
+    x &= 0x1249249249249249ull;
+    x = (x ^ (x >> 2)) & 0x10c30c30c30c30c3ull;
+    x = (x ^ (x >> 4)) & 0x100f00f00f00f00full;
+    x = (x ^ (x >> 8)) & 0x1f0000ff0000ffull;
+    x = (x ^ (x >> 16)) & 0x1f00000000ffffull;
+    x = (x ^ (x >> 32)) & 0x1fffffull;
+    return (unsigned)x;
+}
+// offset of stencil cell t (0..26) from the centre cell; t = 0 is the centre (staged / scanned first)
+__host__ __device__ inline void pct_stencil_cell(int t, int* dx, int* dy, int* dz) {
+    const int i = t == 0 ? 13 : t == 13 ? 0 : t;
+    *dx = i % 3 - 1;
+    *dy = (i / 3) % 3 - 1;
+    *dz = i / 9 - 1;
+}
+// first position of the Morton-sorted code array whose code is >= key
+__device__ inline int64_t pct_code_lower_bound(const unsigned long long* __restrict__ codes, int64_t n, unsigned long long key) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (codes[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
 #define PCT_HIP(ctx, call)                                                        \
     do {                                                                          \
         hipError_t e_ = (call);                                                   \
@@ -198,6 +243,8 @@ int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
 // 27-cell stencil} -- what decides between the plain and the density-adaptive sweep before anything is swept
 int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]);
 int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps);     // pct_levels.hip
+int pct_build_tree(pct_ctx* ctx, int32_t k, double eps);     // pct_tree.hip
+int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps);
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);
 // fit (pct_fit.hip)

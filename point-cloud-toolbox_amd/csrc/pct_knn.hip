@@ -60,6 +60,13 @@ struct KnnArgs {
     int* nbr_cnt;             // nullable
     int* row_done;            // nullable: set to 1 for every row a kernel has answered (level passes)
     int* redo_m;              // nullable (level passes), one slot per table row: why << 29 | candidates the stencil of the row's item held
+    // tree sweep (pct_tree.hip): the cloud in Morton order; a work item is a run of queries of one cell of the
+    // octree level that suits them, its stencil the 27 cells of that level -- 27 contiguous ranges of the cloud
+    const int4* tree_seg;     // per segment {level, cx, cy, cz}
+    const int2* tree_runs;    // per segment 27 x {first position, points}, centre cell first
+    int tree_bits;            // levels below the root (cells per axis at level l: 2^(tree_bits - l)); g = the finest level's grid
+    const unsigned long long* tree_codes;   // Morton code of every position (exact sweep on the tree)
+    const unsigned char* tree_lvl;          // level every position is served at
     int stats;                // collect the counters below (off by default)
     unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries [5] queries beyond the culling limits (always counted)
 };
@@ -471,6 +478,86 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
     }
 }
 
+// Exact sweep on the hierarchical cell list (pct_tree.hip), wave = query of the redo list: the 27 cells of the query's
+// octree level are 27 ranges of the Morton-ordered cloud (found by binary search, one cell per lane); a result the
+// cube cannot vouch for is started over one level up, where the cube is twice as wide -- the root vouches for
+// everything.  Same (fp64 d2, public index) order and the same running list as k_knn_exact.
+template <int R>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact_tree(KnnArgs a, const int* __restrict__ list,
+                                                                        const int* __restrict__ list_count) {
+    __shared__ double s_pend_d[kWavesPerBlock][64 * R + 64];
+    __shared__ int s_pend_p[kWavesPerBlock][64 * R + 64];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int64_t total = list ? (int64_t)*list_count : a.n_owned;
+    const int64_t nwaves = (int64_t)gridDim.x * kWavesPerBlock;
+
+    Sweep<R> sw;
+    sw.k = a.k;
+    sw.eps2 = a.eps2;
+    sw.pts = a.pts;
+    sw.pend_d = s_pend_d[w];
+    sw.pend_p = s_pend_p[w];
+
+    for (int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w; item < total; item += nwaves) {
+        const int row = list ? list[item] : (int)item;          // table row = Morton position of the query
+        const float4 qp = a.pts[row];
+        sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
+        const unsigned long long code = a.tree_codes[row];
+        const int fx = (int)pct_compact3(code), fy = (int)pct_compact3(code >> 1), fz = (int)pct_compact3(code >> 2);
+        int level = __builtin_amdgcn_readfirstlane((int)a.tree_lvl[row]);
+        int rounds = 0;
+        unsigned long long steps = 0;
+        for (;;) {
+            pct_grid g = a.g;
+            g.cell = __builtin_ldexp(a.g.cell, level);
+            g.inv_cell = __builtin_ldexp(a.g.inv_cell, -level);
+            g.nx = g.ny = g.nz = 1 << (a.tree_bits - level);
+            const int cx = __builtin_amdgcn_readfirstlane(fx >> level), cy = __builtin_amdgcn_readfirstlane(fy >> level),
+                      cz = __builtin_amdgcn_readfirstlane(fz >> level);
+            int run_s = 0, run_len = 0;
+            if (lane < 27) {
+                int dx, dy, dz;
+                pct_stencil_cell(lane, &dx, &dy, &dz);
+                const int x = cx + dx, y = cy + dy, z = cz + dz;
+                if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                    const unsigned long long prefix = pct_spread3((unsigned)x) | pct_spread3((unsigned)y) << 1 | pct_spread3((unsigned)z) << 2;
+                    const int64_t lo = pct_code_lower_bound(a.tree_codes, a.n, prefix << (3 * level));
+                    const int64_t hi = pct_code_lower_bound(a.tree_codes, a.n, (prefix + 1) << (3 * level));
+                    run_s = (int)lo;
+                    run_len = (int)(hi - lo);
+                }
+            }
+            sw.reset();
+            for (int t = 0; t < 27; ++t) {
+                const int s0 = __builtin_amdgcn_readlane(run_s, t), s1 = s0 + __builtin_amdgcn_readlane(run_len, t);
+                for (int base = s0; base < s1; base += 64) {
+                    const int pos = base + lane;
+                    const bool valid = pos < s1;
+                    float4 c = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (valid) c = a.pts[pos];
+                    sw.consider(c, pos, valid);
+                    if (sw.npend >= 64 * R) sw.flush();
+                    ++steps;
+                }
+            }
+            if (sw.npend > 0 || sw.empty) sw.flush();
+            const double gx = (sw.qx - g.ox) * g.inv_cell - cx;
+            const double gy = (sw.qy - g.oy) * g.inv_cell - cy;
+            const double gz = (sw.qz - g.oz) * g.inv_cell - cz;
+            if (fmin(sw.tau_d, sw.eps2) <= guaranteed_r2(g, cx, cy, cz, gx, gy, gz, 1) || level >= a.tree_bits) break;
+            ++level;
+            ++rounds;
+        }
+        if (a.stats && lane == 0) {
+            if (rounds > 0) atomicAdd(&a.counters[0], 1ull);
+            atomicAdd(&a.counters[3], steps);
+            atomicMax(&a.counters[6], (steps << 32) | (unsigned)row);      // the costliest query: 64-candidate steps, row
+        }
+        sw.store(row, a.pitch, a.nbr_pos, a.nbr_dist, a.nbr_cnt);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Fast sweep: wave = work item (one cell, <= items_q consecutive queries).
 //
@@ -701,14 +788,19 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
-template <int R, bool EPS, bool PRE, bool PAIR = false, bool Q64 = false>
-__global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
+template <int R, bool EPS, bool PRE, bool PAIR = false, bool Q64 = false, bool TREE = false>
+__global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? 3 : R == 1 ? (Q64 ? 5 : 6) : 4)) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
 #ifndef PCT_STAGE_CAP2
 #define PCT_STAGE_CAP2 768
 #endif
-    constexpr int CAP = R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
+    // (tree items: an octree level changes the population fourfold on a surface, and the window between "cannot vouch
+    // for k+1" and "overflow" must span that with room for the scatter of real counts: 1024 slots, 3 blocks per CU)
+#ifndef PCT_TREE_CAP
+#define PCT_TREE_CAP 1024
+#endif
+    constexpr int CAP = TREE ? PCT_TREE_CAP : R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
     // low bits of a network element: the staged slot of the candidate, or -- pre-selection -- its place in the
     // compacted list of survivors (6 / 7 bits; the slot is looked up in that list afterwards), which leaves three
     // more bits for the key and cuts key collisions eightfold
@@ -730,32 +822,59 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
     if (item >= n_items) return;
     const SortLanes sort_dir = make_sort_lanes();
 
-    const pct_grid g = a.g;
+    pct_grid g = a.g;
     const int* __restrict__ cs = a.cell_start;
     const int2 it2 = items[item];
-    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
-    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
-    const int cx = cell % g.nx;
-    const int cy = (cell / g.nx) % g.ny;
-    const int cz = cell / (g.nx * g.ny);
-    const int qs = cs[cell] + chunk * items_q;                       // owned points sit first in the cell
-    const int qe = min(cs[cell] + a.cell_own[cell], qs + items_q);
-    const int nq = qe - qs;
-    const int row0 = a.own_start[cell] + chunk * items_q;            // neighbour-table row of query qs
-
-    // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+    int cx, cy, cz, qs, nq, row0;
+    constexpr int NRUNS = TREE ? 27 : 9;           // ranges of the cloud the stencil is staged from
+    int run_s = 0, run_len = 0;
     float* cand_x = s_cx[w];
     float* cand_y = s_cy[w];
     float* cand_z = s_cz[w];
     unsigned* pend = s_pend[w];
     int* offc = s_offc[w];
-    int run_s = 0, run_len = 0;
-    if (lane < 9) {
-        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
-        if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
-            const int row = (z * g.ny + y) * g.nx;
-            run_s = cs[row + max(cx - 1, 0)];
-            run_len = cs[row + min(cx + 1, g.nx - 1) + 1] - run_s;
+    if constexpr (TREE) {
+        // item = {first query (Morton position = table row) | (queries - 1) << 26, segment}
+        const int seg = __builtin_amdgcn_readfirstlane(it2.y);
+        if (seg < 0) return;                       // an item of a segment that was split (pct_tree.hip: k_tree_refine)
+        const unsigned packed = (unsigned)__builtin_amdgcn_readfirstlane(it2.x);
+        qs = (int)(packed & 0x3ffffffu);
+        nq = (int)(packed >> 26) + 1;
+        row0 = qs;
+        const int4 hd = a.tree_seg[seg];
+        const int level = __builtin_amdgcn_readfirstlane(hd.x);
+        cx = __builtin_amdgcn_readfirstlane(hd.y);
+        cy = __builtin_amdgcn_readfirstlane(hd.z);
+        cz = __builtin_amdgcn_readfirstlane(hd.w);
+        // the grid of this level: edges scale by exact powers of two, so (x - o) * inv_cell - cx lies in [0, 1) for
+        // every point the Morton code put into the cell
+        g.cell = __builtin_ldexp(a.g.cell, level);
+        g.inv_cell = __builtin_ldexp(a.g.inv_cell, -level);
+        g.nx = g.ny = g.nz = 1 << (a.tree_bits - level);
+        if (lane < 27) {
+            const int2 r = a.tree_runs[(int64_t)seg * 27 + lane];
+            run_s = r.x;
+            run_len = r.y;
+        }
+    } else {
+        const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+        const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+        cx = cell % g.nx;
+        cy = (cell / g.nx) % g.ny;
+        cz = cell / (g.nx * g.ny);
+        qs = cs[cell] + chunk * items_q;                       // owned points sit first in the cell
+        const int qe = min(cs[cell] + a.cell_own[cell], qs + items_q);
+        nq = qe - qs;
+        row0 = a.own_start[cell] + chunk * items_q;            // neighbour-table row of query qs
+
+        // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+        if (lane < 9) {
+            const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+            if (z >= 0 && z < g.nz && y >= 0 && y < g.ny) {
+                const int row = (z * g.ny + y) * g.nx;
+                run_s = cs[row + max(cx - 1, 0)];
+                run_len = cs[row + min(cx + 1, g.nx - 1) + 1] - run_s;
+            }
         }
     }
     // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
@@ -776,7 +895,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
     {
         int acc = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NRUNS; ++t) {
             my_pre = lane == t ? acc : my_pre;
             acc += __builtin_amdgcn_readlane(run_len, t);
         }
@@ -798,7 +917,10 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
     // any of the item's queries -- every point is binned somewhere -- so the item is classified "cells too small"
     // without being swept)
     const bool hopeless = !EPS && a.row_done != nullptr && m < a.k + 1;
-    if (m > CAP || hopeless) {
+    // (tree items: the slot -> position code has four bits per slot, 16 non-empty ranges -- a surface meets about ten
+    // of its 27 stencil cells; more is a volume, where these items pay as little as uniform cells do)
+    const bool crowded = TREE && __popcll(__builtin_amdgcn_ballot_w64(lane < NRUNS && run_len > 0)) > 16;
+    if (m > CAP || hopeless || crowded) {
         // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
         if (a.row_done) {
             // passes of the density-adaptive sweep keep no list: reason and stencil population go to the row's own
@@ -835,11 +957,11 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
         static_assert(CAP / 32 <= 64 * R, "bit string does not fit the list area");
         if (lane < CAP / 32) bits[lane] = 0u;
         wave_lds_sync();
-        const bool nonempty = lane < 9 && run_len > 0;
+        const bool nonempty = lane < NRUNS && run_len > 0;
         const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
         if (nonempty) {
             atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
-            offc[__builtin_amdgcn_mbcnt_lo((unsigned)ne, 0)] = run_s - my_pre;     // lanes 0..8: low word only
+            offc[__builtin_amdgcn_mbcnt_lo((unsigned)ne, 0)] = run_s - my_pre;     // lanes 0..26: low word only
         }
         wave_lds_sync();
         float4 tmp[CAP / 64];
@@ -1259,7 +1381,9 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (R == 1 ? (Q64 ? 5 : 6) : 4)) v
             if (nbp <= LOW) pair_loop(integral_constant<int, LOW>{}, integral_constant<bool, true>{});
             else if (nbp == LOW + 1) pair_loop(integral_constant<int, LOW + 1>{}, integral_constant<bool, false>{});
             else if (PAIRS > LOW + 2 && nbp == LOW + 2) pair_loop(integral_constant<int, (PAIRS > LOW + 2 ? LOW + 2 : PAIRS)>{}, integral_constant<bool, false>{});
-            else pair_loop(integral_constant<int, PAIRS>{}, integral_constant<bool, false>{});
+            // (PAIRS > LOW + 3 -- the 1024-slot staging area of the tree items: the last variant also serves counts it is
+            // not cut for, so it keeps the "is this batch in use" tests; unused batches are not initialised)
+            else pair_loop(integral_constant<int, PAIRS>{}, integral_constant<bool, (PAIRS > LOW + 3)>{});
         }
     } else
     for (int qi = 0; qi < nq; ++qi) {
@@ -1876,6 +2000,51 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             hipLaunchKernelGGL(k_knn_exact<2>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
         PCT_HIP(ctx, hipGetLastError());
     }
+    ctx->knn_sorted_space = true;
+    return PCT_OK;
+}
+
+// Neighbour sweep on the hierarchical cell list (pct_build_tree): fast sweep over its work items, then the exact sweep
+// on the same structure for what the fast one flagged.  The table is in Morton order (a sorted space like the uniform
+// list's: sorted4, owned_pos = identity, row_of).
+int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
+    if (ctx->level_mode || ctx->own_flag || ctx->has_f64 || ctx->q_begin != 0 || ctx->q_end != ctx->n)
+        return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep takes whole float32 clouds");
+    const int64_t n_rows = ctx->n;
+    PCT_TRY(reserve_table(ctx, k, eps));
+    PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
+    KnnArgs a = make_args(ctx, k, eps, true);
+    a.tree_seg = (const int4*)ctx->tree_seg.p;
+    a.tree_runs = (const int2*)ctx->tree_runs.p;
+    a.tree_bits = ctx->tree_bits;
+    a.tree_codes = (const unsigned long long*)ctx->tree_codes.p + ctx->n;     // second half: the sorted codes
+    a.tree_lvl = (const unsigned char*)ctx->tree_lvl.p;
+    int* redo_count = (int*)ctx->counters.p + 14;
+    int* redo = (int*)ctx->redo.p;
+    const int2* items = (const int2*)ctx->occ.p;
+    const bool r1 = k + 1 <= pct_fast_r1_max();
+    const bool exact_only = getenv("PCT_TREE_EXACT_ONLY") != nullptr;        // testing: every query through the exact sweep
+    if (ctx->n_items > 0 && !exact_only) {
+        const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
+        const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
+        const bool e = eps > 0;
+#define PCT_TREE(R_, E_, GRID_, BLOCK_) \
+    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, false, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (r1 && !e) PCT_TREE(1, false, grid1, block1);
+        else if (r1) PCT_TREE(1, true, grid1, block1);
+        else if (!e) PCT_TREE(2, false, grid2, block2);
+        else PCT_TREE(2, true, grid2, block2);
+#undef PCT_TREE
+        PCT_HIP(ctx, hipGetLastError());
+    }
+    PCT_HIP(ctx, hipEventRecord(ctx->ev[7], ctx->stream));
+    const int blocks = (32768 + kWavesPerBlock - 1) / kWavesPerBlock;        // device-side count, fixed grid
+    const int* list = exact_only ? nullptr : redo;
+    if (k + 1 <= 64)
+        hipLaunchKernelGGL(k_knn_exact_tree<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
+    else
+        hipLaunchKernelGGL(k_knn_exact_tree<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
+    PCT_HIP(ctx, hipGetLastError());
     ctx->knn_sorted_space = true;
     return PCT_OK;
 }

@@ -28,7 +28,7 @@ from . import _capi
 __all__ = ["PointCloud"]
 
 _ALGORITHMS = {"auto": _capi.KNN_AUTO, "brute": _capi.KNN_BRUTE, "grid": _capi.KNN_GRID,
-               "grid_exact": _capi.KNN_GRID_EXACT, "grid_levels": _capi.KNN_GRID_LEVELS}
+               "grid_exact": _capi.KNN_GRID_EXACT, "grid_levels": _capi.KNN_GRID_LEVELS, "tree": _capi.KNN_TREE}
 
 
 def _matrix_norms(points):

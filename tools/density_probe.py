@@ -42,6 +42,24 @@ for name, p in clouds.items():
         t = h.timings()
         if lv is None or t["total_ms"] < lv["total_ms"]:
             lv = t
+    h.set_stats(True)
+    h.curvature(50, 0.0, _capi.KNN_TREE)
+    ts = h.timings()
+    h.set_stats(False)
+    tr = None
+    for _ in range(3):
+        h.curvature(50, 0.0, _capi.KNN_TREE)
+        t = h.timings()
+        if tr is None or t["total_ms"] < tr["total_ms"]:
+            tr = t
+    if os.environ.get("PCT_PROBE_CHECK"):              # same bits as the plain sweep? (both are exact)
+        _, Kt, Ht, _ = h.get_fit(0, len(p), coefs=False, H2=False)
+        it, dt, _ = h.get_neighbors(0, min(len(p), 200000))
+        h.curvature(50, 0.0, _capi.KNN_GRID)
+        _, Kg, Hg, _ = h.get_fit(0, len(p), coefs=False, H2=False)
+        ig, dg, _ = h.get_neighbors(0, min(len(p), 200000))
+        print(f"{name:22s} TREE == GRID: idx {np.array_equal(it, ig)} dist {np.array_equal(dt, dg)} K {np.array_equal(Kt, Kg, equal_nan=True)} H {np.array_equal(Ht, Hg, equal_nan=True)}")
+    print(f"{name:22s} TREE   total {tr['total_ms']:8.3f} ms knn {tr['knn_ms']:.3f} (fast {tr['knn_fast_ms']:.3f}) fit {tr['fit_ms']:.3f} build {tr['grid_ms']:.3f} | items {tr['occupied_cells']} segments {tr['cells']} redo {ts['redone_queries']} ovf-items {ts['lds_overflows']} up-level {ts['ring_fallbacks']}")
     au = None
     for _ in range(3):
         h.curvature(50, 0.0, _capi.KNN_AUTO)
