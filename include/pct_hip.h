@@ -36,14 +36,14 @@ enum pct_knn_algo {
     PCT_KNN_GRID = 2,         /* uniform cell list, LDS-staged 27-cell stencil          */
     PCT_KNN_GRID_EXACT = 3,   /* same cell list, every query through the exact sweep    */
     PCT_KNN_GRID_LEVELS = 4,  /* chain of cell lists, each sized for the queries the previous
-                                 one could not answer (clouds of very uneven density);
-                                 PCT_KNN_AUTO takes it by itself where a census of the work
-                                 items predicts that it pays (surface-like clouds whose
-                                 density spans decades)                                  */
+                                 one could not answer (clouds of very uneven density)    */
     PCT_KNN_TREE = 5          /* hierarchical cell list: the cloud in Morton order, every
-                                 query served at the octree level that suits its density;
-                                 what it cannot prove goes down the chain above (whole
-                                 float32 clouds; otherwise the same as GRID_LEVELS)      */
+                                 query swept at the octree level that suits ITS density
+                                 (whole float32 clouds below 2^26 points; anything else
+                                 asked for it takes GRID_LEVELS).  PCT_KNN_AUTO takes it
+                                 by itself where a census of the uniform list's work items
+                                 predicts that it pays: surface-like clouds whose density
+                                 spans a decade or more                                  */
 };
 
 /* Per-stage device times of the most recent call, hipEvent milliseconds. */
@@ -73,6 +73,8 @@ typedef struct pct_timings {
     double occupancy;         /* mean number of points sharing a point's cell (the cell-size search steers on it) */
     int64_t fit_svd_rows;     /* rows of the last fit solved by the SVD kernel (lstsq's gelsd semantics: ill-conditioned
                                  or under-determined design matrices) instead of the normal equations */
+    int32_t algo;             /* the sweep that produced the table in place (pct_knn_algo; what PCT_KNN_AUTO chose) */
+    int32_t reserved;
 } pct_timings;
 
 /* ---- lifetime ---------------------------------------------------------- */

@@ -38,6 +38,7 @@ class Timings(C.Structure):
         ("grid_points", C.c_int64), ("limit_retries", C.c_int32), ("levels", C.c_int32),
         ("occupancy", C.c_double),
         ("fit_svd_rows", C.c_int64),
+        ("algo", C.c_int32), ("reserved", C.c_int32),
     ]
 
     def as_dict(self):

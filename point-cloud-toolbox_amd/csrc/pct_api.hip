@@ -218,7 +218,9 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     ctx->eps = eps;
     PCT_HIP(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
     ctx->tm.levels = 0;
+    ctx->tm.algo = algo;
     const auto run_levels = [&]() -> int {
+        ctx->tm.algo = PCT_KNN_GRID_LEVELS;
         PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         ctx->levels_fuse_fit = fuse_fit;
         const int lst = pct_knn_levels(ctx, k, eps);
@@ -234,8 +236,11 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     // the hierarchical cell list takes whole float32 clouds; anything else goes down the chain of cell lists
     const bool tree_ok = !ctx->has_f64 && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n < ((int64_t)1 << 26);
     const auto run_tree = [&]() -> int {
+        ctx->tm.algo = PCT_KNN_TREE;
         ctx->last_levels = false;
-        PCT_TRY(pct_build_tree(ctx, k, eps));
+        bool usable = false;
+        PCT_TRY(pct_build_tree(ctx, k, eps, &usable));
+        if (!usable) return run_levels();          // (extents or eps outside what the float32 pre-selection can square)
         PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         PCT_TRY(pct_launch_knn_tree(ctx, k, eps));
         PCT_HIP(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
@@ -265,7 +270,10 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 const double q = (double)(c[0] ? c[0] : 1), fail = (double)(c[1] + c[2]) / q, fine = (double)c[0] - (double)(c[1] + c[2]);
                 const double cells = fine > 0 ? (double)c[3] / fine : 27.0;
                 if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
-                if (fail > 0.30 && fine > 0.02 * q && cells < 15.0) return run_levels();
+                // (the hierarchical list costs ~1.7x a uniform one whatever the density; every query the uniform list
+                // would hand to the exact sweep costs about as much as twelve it answers itself)
+                if (tree_ok && !getenv("PCT_NO_TREE") ? fail > 0.12 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0)
+                    return tree_ok && !getenv("PCT_NO_TREE") ? run_tree() : run_levels();
             }
         }
     } else {

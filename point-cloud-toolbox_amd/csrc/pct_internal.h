@@ -243,7 +243,7 @@ int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps);
 // 27-cell stencil} -- what decides between the plain and the density-adaptive sweep before anything is swept
 int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]);
 int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps);     // pct_levels.hip
-int pct_build_tree(pct_ctx* ctx, int32_t k, double eps);     // pct_tree.hip
+int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable);     // pct_tree.hip (usable = false: not a cloud for it, nothing was built)
 int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps);
 int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end,
                                 int32_t* d_idx, float* d_dist, int32_t* d_cnt);

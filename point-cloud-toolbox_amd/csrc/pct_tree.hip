@@ -261,15 +261,22 @@ struct MaxInt {
 // Morton order, levels, segments, items and stencil ranges of the whole cloud (public rows [0, n) all owned).
 // Leaves: sorted4 (Morton order), owned_pos (identity: table row = Morton position), occ (items + sentinel),
 // tree_seg / tree_runs, grid = the FINEST level's grid, n_items.
-int pct_build_tree(pct_ctx* ctx, int32_t k, double eps) {
+int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     const int64_t n = ctx->n;
     float bbox[6];
+    *usable = false;
     PCT_TRY(pct_pack_points(ctx, bbox));                 // pts4 (public order) + bounding box; refuses non-finite input
     if (ctx->n_grid != n) return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep needs the whole cloud packed");
     double ext = 0;
     for (int a = 0; a < 3; ++a) ext = fmax(ext, (double)bbox[3 + a] - bbox[a]);
     if (!(ext > 0)) ext = 1.0;
     const double root = ext * (1.0 + 0x1p-18);           // every coordinate strictly inside the cube
+    // The sweep pre-selects in float32: squared differences of up to three cell edges of ANY level, and the squared
+    // eps radius, must neither overflow nor underflow there (the uniform list has a float64-keyed variant for such
+    // clouds; here they are left to it).
+    const double fine2 = ldexp(root, -kTreeBits) * ldexp(root, -kTreeBits);
+    if (!(fine2 > 1e-30) || !(root * root < 1e30) || (eps > 0 && !(eps * eps > 1e-36))) return PCT_OK;
+    *usable = true;
     pct_grid g = {};
     g.ox = bbox[0]; g.oy = bbox[1]; g.oz = bbox[2];
     g.cell = ldexp(root, -kTreeBits);

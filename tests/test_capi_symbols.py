@@ -34,8 +34,8 @@ def test_binding_table_matches_header(built):
 
 def test_timings_struct_layout(built):
     # pct_timings: 7 floats, 2 int32 (+ 4 bytes of padding to 8-byte alignment), 7 int64, 1 double, 1 int64,
-    # 2 int32, 1 double, 1 int64  (include/pct_hip.h) -- and what the library itself was compiled with
-    assert ctypes.sizeof(built["capi"].Timings) == 7 * 4 + 2 * 4 + 4 + 7 * 8 + 8 + 8 + 2 * 4 + 8 + 8
+    # 2 int32, 1 double, 1 int64, 2 int32  (include/pct_hip.h) -- and what the library itself was compiled with
+    assert ctypes.sizeof(built["capi"].Timings) == 7 * 4 + 2 * 4 + 4 + 7 * 8 + 8 + 8 + 2 * 4 + 8 + 8 + 2 * 4
     assert built["capi"].load().pct_timings_size() == ctypes.sizeof(built["capi"].Timings)
 
 

@@ -971,11 +971,14 @@ def test_rccl_exchange_of_unequal_shards_in_process(gpu):
     h.close()
 
 
+@pytest.mark.parametrize("algo", ["levels", "tree"])
 @pytest.mark.parametrize("kind", ["blobs", "outliers", "shell_and_core", "quantised"])
-def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind):
-    """PCT_KNN_GRID_LEVELS (each pass owns what the previous one could not answer) against the exhaustive sweep, bit
-    for bit, neighbours and curvatures, also for a shard and with the eps bound."""
+def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind, algo):
+    """PCT_KNN_GRID_LEVELS (each pass owns what the previous one could not answer) and PCT_KNN_TREE (the hierarchical
+    cell list) against the exhaustive sweep, bit for bit, neighbours and curvatures, also for a shard (the tree
+    takes whole clouds: a shard asked of it goes down the chain) and with the eps bound."""
     capi = gpu["capi"]
+    which = capi.KNN_GRID_LEVELS if algo == "levels" else capi.KNN_TREE
     for n, k, eps in ((30_000, 30, 0.0), (20_000, 70, 0.0), (25_000, 25, 0.05)):
         pts = _stress_cloud(kind, np.random.default_rng([len(kind), n, 7]), n)
         h = capi.Handle(0)
@@ -983,23 +986,24 @@ def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind):
         h.curvature(k, eps, capi.KNN_BRUTE)
         ib, db, cb = h.get_neighbors(0, n, want_count=True)
         cfb, Kb, Hb, _ = h.get_fit(0, n)
-        h.curvature(k, eps, capi.KNN_GRID_LEVELS)
-        assert h.timings()["levels"] >= 1
+        h.curvature(k, eps, which)
+        assert h.timings()["algo"] == which and (algo == "tree" or h.timings()["levels"] >= 1)
         il, dl, cl = h.get_neighbors(0, n, want_count=True)
         cfl, Kl, Hl, _ = h.get_fit(0, n)
         assert np.array_equal(ib, il) and np.array_equal(db, dl) and np.array_equal(cb, cl), (kind, n, k, eps)
         assert np.array_equal(cfb, cfl, equal_nan=True) and np.array_equal(Kb, Kl, equal_nan=True) and np.array_equal(Hb, Hl, equal_nan=True)
         lo, hi = n // 3, n // 3 + n // 4
         h.set_query_range(lo, hi)
-        h.knn(k, eps=eps, algo=capi.KNN_GRID_LEVELS)
+        h.knn(k, eps=eps, algo=which)
+        assert h.timings()["algo"] == capi.KNN_GRID_LEVELS
         i2, d2, c2 = h.get_neighbors(lo, hi, want_count=True)
         assert np.array_equal(i2, ib[lo:hi]) and np.array_equal(d2, db[lo:hi]) and np.array_equal(c2, cb[lo:hi])
         h.close()
 
 
-def test_auto_takes_the_chain_of_cell_lists_only_where_it_pays(gpu):
+def test_auto_takes_the_hierarchical_cell_list_only_where_it_pays(gpu):
     """PCT_KNN_AUTO: a scan whose density falls off like 1/r^2 (one terrestrial laser station) goes through the
-    density-adaptive sweep, an even surface and a volume do not -- and whatever is chosen, the values are the same."""
+    hierarchical cell list, an even surface and a volume do not -- and whatever is chosen, the values are the same."""
     capi = gpu["capi"]
     rng = np.random.default_rng(8)
     n = 400_000
@@ -1010,17 +1014,65 @@ def test_auto_takes_the_chain_of_cell_lists_only_where_it_pays(gpu):
         h = capi.Handle(0)
         h.set_points(pts)
         h.curvature(40, 0.0, capi.KNN_AUTO)
-        levels = h.timings()["levels"]
-        assert (levels > 0) == (name == "lidar"), (name, levels)
+        chosen = h.timings()["algo"]
+        assert chosen == (capi.KNN_TREE if name == "lidar" else capi.KNN_GRID), (name, chosen)
         rows = np.arange(0, n, 41)
         ia, da, _ = h.get_neighbor_rows(rows)
         _, Ka, Ha, _ = h.get_fit(0, n, coefs=False, H2=False)
         h.curvature(40, 0.0, capi.KNN_GRID)
-        assert h.timings()["levels"] == 0
+        assert h.timings()["algo"] == capi.KNN_GRID
         ib, db, _ = h.get_neighbor_rows(rows)
         _, Kb, Hb, _ = h.get_fit(0, n, coefs=False, H2=False)
         assert np.array_equal(ia, ib) and np.array_equal(da, db)
         assert np.array_equal(Ka, Kb, equal_nan=True) and np.array_equal(Ha, Hb, equal_nan=True)
+        h.close()
+
+
+def test_hierarchical_cell_list_on_awkward_clouds(gpu, monkeypatch):
+    """PCT_KNN_TREE against the exhaustive sweep where its parts are strained: clouds smaller than a work item, every
+    point identical (one Morton code: the level cannot go below 0), a line (one non-empty stencil cell in three), the
+    reference's theta x phi lattice (equal keys everywhere), a lone point far from everything (its own cell is empty
+    at every level: found by the 10:1 density probe, where one such query scanned the whole cloud), k up to 127 and
+    the eps bound; and its exact sweep alone (PCT_TREE_EXACT_ONLY) on one of them."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    rng = np.random.default_rng(77)
+    plane = np.concatenate([rng.uniform(-1, 0, (60_000, 2)), rng.uniform(0, 1, (6_000, 2))])
+    two = np.stack([plane[:, 0], plane[:, 1], 0.05 * np.sin(plane[:, 0]) * np.cos(plane[:, 1])], 1).astype(np.float32)
+    two[-1] = (0.9, -0.9, 0.0)                        # alone in its quadrant
+    line = np.stack([np.linspace(0, 1, 5000), np.zeros(5000), np.zeros(5000)], 1).astype(np.float32)
+    cases = [
+        ("tiny", rng.normal(size=(7, 3)).astype(np.float32), 5, 0.0),
+        ("small", rng.normal(size=(130, 3)).astype(np.float32), 60, 0.0),
+        ("identical", np.ones((3000, 3), np.float32), 20, 0.0),
+        ("line", line, 30, 0.0),
+        ("lattice", shapes.torus_grid(150), 50, 0.0),
+        ("two densities + loner", two, 50, 0.0),
+        ("two densities, k=127", two, 127, 0.0),
+        ("two densities, eps", two, 40, 0.02),
+        ("torus, eps smaller than the spacing", shapes.torus_random(20_000, seed=3), 10, 0.004),
+    ]
+    for name, pts, k, eps in cases:
+        n = len(pts)
+        h = capi.Handle(0)
+        h.set_points(pts)
+        h.curvature(k, eps, capi.KNN_BRUTE)
+        ib, db, cb = h.get_neighbors(0, n, want_count=True)
+        _, Kb, Hb, _ = h.get_fit(0, n, coefs=False, H2=False)
+        h.curvature(k, eps, capi.KNN_TREE)
+        assert h.timings()["algo"] == capi.KNN_TREE, name
+        it, dt, ct = h.get_neighbors(0, n, want_count=True)
+        _, Kt, Ht, _ = h.get_fit(0, n, coefs=False, H2=False)
+        assert np.array_equal(ib, it) and np.array_equal(db, dt) and np.array_equal(cb, ct), name
+        assert np.array_equal(Kb, Kt, equal_nan=True) and np.array_equal(Hb, Ht, equal_nan=True), name
+        rows = np.arange(0, n, max(1, n // 50))       # the row-wise download goes through row_of
+        ir, dr, _ = h.get_neighbor_rows(rows)
+        assert np.array_equal(ir, ib[rows]) and np.array_equal(dr, db[rows]), name
+        if name == "two densities + loner":
+            monkeypatch.setenv("PCT_TREE_EXACT_ONLY", "1")
+            h.knn(k, eps=eps, algo=capi.KNN_TREE)
+            monkeypatch.delenv("PCT_TREE_EXACT_ONLY")
+            ie, de, _ = h.get_neighbors(0, n)
+            assert np.array_equal(ib, ie) and np.array_equal(db, de), name + " (exact sweep on the tree)"
         h.close()
 
 
@@ -1046,8 +1098,8 @@ def test_chain_window_and_histogram_agree_at_a_bin_boundary(gpu):
 
 
 def test_pointcloud_flow_on_a_lidar_like_scan(gpu):
-    """The class surface on a cloud whose density falls off like 1/r^2 (default algorithm: the chain of cell lists is
-    taken by itself): planting, lazy neighbour download, neighbour study, separate fit, curvatures -- against the
+    """The class surface on a cloud whose density falls off like 1/r^2 (default algorithm: the hierarchical cell list
+    is taken by itself): planting, lazy neighbour download, neighbour study, separate fit, curvatures -- against the
     oracle on sampled rows."""
     rng = np.random.default_rng(18)
     n = 200_000
@@ -1056,7 +1108,7 @@ def test_pointcloud_flow_on_a_lidar_like_scan(gpu):
     pts = np.stack([x, y, 0.1 * np.sin(2 * x) * np.cos(2 * y)], 1).astype(np.float32)
     pc = gpu["PointCloud"](points=pts, normals=np.zeros((n, 0)))
     pc.plant_kdtree(100)
-    assert pc.last_timings["levels"] > 0
+    assert pc.last_timings["algo"] == gpu["capi"].KNN_TREE
     np.random.seed(3)
     conv = pc.explicit_quadratic_neighbor_study(sample_size=30)
     np.random.seed(3)

@@ -11,7 +11,7 @@ import __graft_entry__ as ge
 ge.build()
 from point_cloud_toolbox_amd import _capi, shapes
 
-ALGOS = [_capi.KNN_GRID, _capi.KNN_GRID, _capi.KNN_BRUTE, _capi.KNN_GRID_EXACT, _capi.KNN_GRID_LEVELS]
+ALGOS = [_capi.KNN_GRID, _capi.KNN_GRID, _capi.KNN_BRUTE, _capi.KNN_GRID_EXACT, _capi.KNN_GRID_LEVELS, _capi.KNN_TREE]
 
 
 def new_cloud(rng):

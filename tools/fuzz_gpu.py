@@ -68,7 +68,7 @@ def run(seed0, budget=None, cases=None, verbose=True):
       t_brute = time.time() - t_case
       ib, db, cb = h.get_neighbors(0, n, want_count=True)
       cfb, Kb, Hb, _ = h.get_fit(0, n)
-      for algo, name in ((_capi.KNN_GRID, "grid"), (_capi.KNN_GRID_LEVELS, "levels")):
+      for algo, name in ((_capi.KNN_GRID, "grid"), (_capi.KNN_GRID_LEVELS, "levels"), (_capi.KNN_TREE, "tree")):
           if name == "levels" and rng.random() < 0.5:
               continue
           h.curvature(k, eps, algo)

@@ -14,7 +14,7 @@ print("case", n, k, kind, eps, pts.dtype)
 h = _capi.Handle(0); h.set_points(pts)
 h.curvature(k, eps, _capi.KNN_BRUTE)
 ib, db, cb = h.get_neighbors(0, n, want_count=True); cfb, Kb, Hb, _ = h.get_fit(0, n)
-for algo, name in ((_capi.KNN_GRID, "grid"), (_capi.KNN_GRID_LEVELS, "levels")):
+for algo, name in ((_capi.KNN_GRID, "grid"), (_capi.KNN_GRID_LEVELS, "levels"), (_capi.KNN_TREE, "tree")):
     h.curvature(k, eps, algo)
     ig, dg, cg = h.get_neighbors(0, n, want_count=True); cfg, Kg, Hg, _ = h.get_fit(0, n)
     bad_i = np.where((ib != ig).any(1))[0]; bad_d = np.where((db != dg).any(1))[0]; bad_c = np.where(cb != cg)[0]

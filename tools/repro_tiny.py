@@ -20,7 +20,7 @@ for it in range(first, last):
     if rng.random() < 0.2:
         mag = 10.0 ** rng.uniform(-30, 30); pts = (pts.astype(np.float64) * mag).astype(pts.dtype); eps *= mag
     h = _capi.Handle(0); h.set_points(pts)
-    for algo in (_capi.KNN_BRUTE, _capi.KNN_GRID, _capi.KNN_GRID_LEVELS, _capi.KNN_GRID_EXACT):
+    for algo in (_capi.KNN_BRUTE, _capi.KNN_GRID, _capi.KNN_GRID_LEVELS, _capi.KNN_GRID_EXACT, _capi.KNN_TREE):
         print(f"case {it} n={n} k={k} kind={kind} eps={eps} dtype={pts.dtype} algo={algo}", flush=True)
         h.curvature(k, eps, algo)
         h.get_fit(0, n)
