@@ -170,6 +170,45 @@ def secondary_lattice(capi, shapes, k):
                          "knn_fast_kernel": acc["knn_fast_ms"] / steps, "fit_curvature": acc["fit_ms"] / steps}}
 
 
+def secondary_uneven(capi, k):
+    """A cloud whose density spans four decades -- a plane seen from one terrestrial laser station, density ~ 1/r^2 for
+    r = 0.01 ... 1 -- through PCT_KNN_AUTO (default algorithm of the class surface): the census sends it to the
+    hierarchical cell list.  A uniform cell list runs this cloud 13x slower (tools/density_probe.py)."""
+    rng = np.random.default_rng(5)
+    n = 1_000_000
+    r, a = 0.01 * 100 ** rng.uniform(0, 1, n), rng.uniform(0, 2 * np.pi, n)
+    x, y = r * np.cos(a), r * np.sin(a)
+    pts = np.ascontiguousarray(np.stack([x, y, 0.05 * np.sin(x) * np.cos(y)], 1), dtype=np.float32)
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.set_stats(True)
+    h.curvature(k, 0.0, capi.KNN_AUTO)
+    t = h.timings()
+    redone, algo = t["redone_queries"], t["algo"]
+    h.set_stats(False)
+    for _ in range(3):
+        h.curvature(k, 0.0, capi.KNN_AUTO)
+    steps = 10
+    h.synchronize()
+    t0 = time.perf_counter()
+    acc = {"grid_ms": 0.0, "knn_ms": 0.0, "knn_fast_ms": 0.0, "fit_ms": 0.0}
+    for _ in range(steps):
+        h.curvature(k, 0.0, capi.KNN_AUTO)
+        t = h.timings()
+        for key in acc:
+            acc[key] += t[key]
+    h.synchronize()
+    dt = time.perf_counter() - t0
+    h.close()
+    names = {capi.KNN_GRID: "uniform cell list", capi.KNN_GRID_LEVELS: "chain of cell lists", capi.KNN_TREE: "hierarchical cell list"}
+    return {"workload": "plane scanned from one station: 1 M points, density ~ 1/r^2 over r = 0.01..1, float32, k=%d, PCT_KNN_AUTO" % k,
+            "algorithm": names.get(algo, str(algo)),
+            "value": n * steps / dt, "unit": "points/s", "ms_per_step": 1e3 * dt / steps, "steps": steps,
+            "redo_fraction": redone / n,
+            "stage_ms": {"build": acc["grid_ms"] / steps, "knn": acc["knn_ms"] / steps,
+                         "knn_fast_kernel": acc["knn_fast_ms"] / steps, "fit_curvature": acc["fit_ms"] / steps}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -271,9 +310,10 @@ def main():
     # The secondary measurement (the reference's own lattice torus, its own handle) runs BEFORE the headline region: its
     # order is free, and a GPU that has just worked holds its clocks -- the W warm-up steps alone (3 ms) leave the first
     # region 5-6 % slower than the same region repeated (repeat_ms_per_step).
-    secondary = None
+    secondary = uneven = None
     if world == 1 and not dist_mode and not args.no_extras and args.config == "c3":
         secondary = secondary_lattice(_capi, shapes, k)
+        uneven = secondary_uneven(_capi, k)
     for _ in range(args.warmup):
         step()
     dt, acc, last_tm = timed_region(args.steps)
@@ -364,6 +404,8 @@ def main():
             out["verified"] = verified
         if secondary is not None:
             out["secondary"] = secondary
+        if uneven is not None:
+            out["secondary_uneven_density"] = uneven
         if world == 1 and not args.no_cpu_baseline and args.config == "c3":
             out["cpu_baseline"] = cpu_baseline(local, k)
             out["cpu_baseline"]["host_cpus"] = os.cpu_count()

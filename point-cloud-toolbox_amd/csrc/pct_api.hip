@@ -249,6 +249,10 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         return PCT_OK;
     };
     if (algo == PCT_KNN_TREE) return tree_ok ? run_tree() : run_levels();
+    // a handle fed a stream of similar clouds: what the census said about the last one of this size still holds
+    if (auto_req && tree_ok && ctx->auto_tree_n == ctx->n && (++ctx->auto_tree_calls & 15) != 0 && !getenv("PCT_NO_TREE") &&
+        !getenv("PCT_NO_AUTO_LEVELS"))
+        return run_tree();
     if (algo == PCT_KNN_GRID_LEVELS) return run_levels();
     ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
@@ -264,6 +268,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
             ctx->nonempty_cells > 0 && !getenv("PCT_NO_AUTO_LEVELS")) {
             const double skew = ctx->tm.occupancy * (double)ctx->nonempty_cells / (double)ctx->n;
             if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] occupancy %.1f, %lld non-empty cells, skew %.2f\n", ctx->tm.occupancy, (long long)ctx->nonempty_cells, skew);
+            if (!(skew > 1.5)) ctx->auto_tree_n = 0;
             if (skew > 1.5) {
                 unsigned long long c[4];
                 PCT_TRY(pct_item_census(ctx, k, c));
@@ -272,8 +277,11 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
                 // (the hierarchical list costs ~1.7x a uniform one whatever the density; every query the uniform list
                 // would hand to the exact sweep costs about as much as twelve it answers itself)
-                if (tree_ok && !getenv("PCT_NO_TREE") ? fail > 0.12 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0)
-                    return tree_ok && !getenv("PCT_NO_TREE") ? run_tree() : run_levels();
+                if (tree_ok && !getenv("PCT_NO_TREE") ? fail > 0.12 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
+                    if (tree_ok && !getenv("PCT_NO_TREE")) { ctx->auto_tree_n = ctx->n; return run_tree(); }
+                    return run_levels();
+                }
+                ctx->auto_tree_n = 0;
             }
         }
     } else {

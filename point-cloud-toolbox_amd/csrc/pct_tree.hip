@@ -1,24 +1,33 @@
-// Hierarchical cell list: the cloud in Morton order, every query served at the octree level that suits ITS density.
+// Hierarchical cell list: the cloud in Morton order, every query swept at the octree level that suits ITS density.
 //
 // One cell size serves one density (pct_grid.hip); a chain of cell lists (pct_levels.hip) serves one octave of
 // densities per pass and pays a build, a merge and two read-backs for each.  Here the points are sorted ONCE, by the
 // Morton code of their position in a 2^21-cube over the bounding box.  A cell of ANY octree level is then a
 // contiguous range of the sorted cloud, and so is every cell of its 27-cell stencil: the fast sweep stages 27 ranges
 // instead of 9 x-runs and everything behind the staging -- pre-selection, keys, network, proofs -- is the code the
-// uniform cell list runs (k_knn_fast<..., TREE>).
+// uniform cell list runs (k_knn_fast<..., TREE>, pct_knn.hip).
 //
-//   level of a point   the finest level whose cell around it holds >= n_min points (n_min ~ 0.45 (k+1): on a surface
-//                      the disc the 27-cell cube vouches for then holds about k+1).  Found without a tree: the cell
-//                      of a point is a run of its neighbours in Morton order, and how far the run reaches at level l
-//                      follows from the highest differing bit against each neighbour -- a merge of two monotone
-//                      sequences, n_min loads.
+//   level of a point   first guess: the finest level whose cell around it holds >= n_min points (n_min ~ 0.45 (k+1):
+//                      on a surface the disc the 27-cell cube vouches for then holds about k+1).  Found without a
+//                      tree: the cell of a point is a run of its neighbours in Morton order, and how far the run
+//                      reaches at level l follows from the highest differing bit against each neighbour -- a merge
+//                      of two monotone sequences, n_min loads (k_tree_level).
 //   segment            a maximal run of consecutive points with the same level and the same cell of that level;
-//   work item          <= items_q consecutive queries of a segment (as in the uniform list);
-//   stencil            per segment 27 {first position, points}: two binary searches in the code array per cell.
+//   stencil            per segment 27 {first position, points}: two binary searches in the code array per cell
+//                      (k_tree_stencil);
+//   refinement         the own cell says nothing about the neighbours: a sparse cell next to dense ones (the rim of
+//                      the cloud, a lone point -- whose own cell is "full" only at the root) gets a stencil far over
+//                      the staging capacity.  Such segments are split octant by octant until every piece fits
+//                      (k_tree_refine: one wave per segment walks its run depth first); stencil populations are
+//                      monotone in the level, so this ends, at the latest at level 0;
+//   work item          <= items_q consecutive queries of a segment, {first query | count, segment}.
 //
-// Rows the sweep cannot prove (stencil over the staging cap, too few points inside the guaranteed radius, more than
-// 16 non-empty stencil cells) are left to the chain's later passes and the exact sweep: pct_knn_levels runs this as
-// its first pass.  The sort is rocPRIM's device radix sort; the scans are rocPRIM's too.
+// What the fast sweep cannot prove (too few points inside the radius its cube vouches for, more than 16 non-empty
+// stencil cells, a level-0 pile over the capacity) goes to k_knn_exact_tree: the same 27 ranges from global memory,
+// one level up whenever the cube cannot vouch for the list -- the root vouches for everything.
+// Bit-identical to the exhaustive sweep (tests/test_gpu_parity.py: test_hierarchical_cell_list_on_awkward_clouds,
+// test_chain_of_cell_lists_equals_exhaustive_sweep[tree], the fuzzers).  The sort and the two scans are rocPRIM's
+// device primitives; everything else here is hand-written.
 #include "pct_internal.h"
 
 #include <cstring>
@@ -363,7 +372,10 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     if (n_items <= 0 || n_items > n || n_segs <= 0 || n_segs > n_items)
         return pct_fail(ctx, PCT_ERR_INVALID, "tree build: %lld items in %lld segments for %lld points", (long long)n_items, (long long)n_segs, (long long)n);
     // staging capacity of the sweep that will run (k_knn_fast<..., TREE>)
-    int cap = k + 1 <= pct_fast_r1_max() ? 1024 : 768;
+#ifndef PCT_TREE_CAP
+#define PCT_TREE_CAP 768
+#endif
+    int cap = PCT_TREE_CAP;
     if (const char* e = getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
     size_t room = (size_t)n_segs + nn / 8 + 64;           // segments the range table has room for
     PCT_TRY(pct_reserve(ctx, &ctx->tree_runs, room * 27 * sizeof(int2)));
@@ -411,7 +423,6 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     ctx->n_occ = n_items;
     ctx->tree_segs = n_segs;
     ctx->nonempty_cells = n_segs;
-    for (int a = 0; a < 6; ++a) ctx->lvl_bbox[a] = bbox[a];
     ctx->tm.grid_iters = 1;
     ctx->tm.cells = n_segs;
     ctx->tm.cell_size = g.cell;
