@@ -39,8 +39,8 @@ enum pct_knn_algo {
                                  one could not answer (clouds of very uneven density)    */
     PCT_KNN_TREE = 5          /* hierarchical cell list: the cloud in Morton order, every
                                  query swept at the octree level that suits ITS density
-                                 (whole float32 clouds below 2^26 points; anything else
-                                 asked for it takes GRID_LEVELS).  PCT_KNN_AUTO takes it
+                                 (whole clouds below 2^26 points; anything else asked for
+                                 it takes GRID_LEVELS).  PCT_KNN_AUTO takes it
                                  by itself where a census of the uniform list's work items
                                  predicts that it pays: surface-like clouds whose density
                                  spans a decade or more                                  */

@@ -233,8 +233,8 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         ctx->last_levels = true;
         return PCT_OK;
     };
-    // the hierarchical cell list takes whole float32 clouds; anything else goes down the chain of cell lists
-    const bool tree_ok = !ctx->has_f64 && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n < ((int64_t)1 << 26);
+    // the hierarchical cell list takes whole clouds; a shard asked of it goes down the chain of cell lists
+    const bool tree_ok = ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n < ((int64_t)1 << 26);
     const auto run_tree = [&]() -> int {
         ctx->tm.algo = PCT_KNN_TREE;
         ctx->last_levels = false;

@@ -504,8 +504,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact_tree(KnnArgs 
 
     for (int64_t item = (int64_t)blockIdx.x * kWavesPerBlock + w; item < total; item += nwaves) {
         const int row = list ? list[item] : (int)item;          // table row = Morton position of the query
-        const float4 qp = a.pts[row];
-        sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
+        if (a.ptsd) {                               // float64 clouds: native query, float32-rounded candidates (pct:74, 83)
+            const double4 qd = a.ptsd[row];
+            sw.qx = qd.x; sw.qy = qd.y; sw.qz = qd.z;
+        } else {
+            const float4 qp = a.pts[row];
+            sw.qx = (double)qp.x; sw.qy = (double)qp.y; sw.qz = (double)qp.z;
+        }
         const unsigned long long code = a.tree_codes[row];
         const int fx = (int)pct_compact3(code), fy = (int)pct_compact3(code >> 1), fz = (int)pct_compact3(code >> 2);
         int level = __builtin_amdgcn_readfirstlane((int)a.tree_lvl[row]);
@@ -2010,8 +2015,8 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
 // on the same structure for what the fast one flagged.  The table is in Morton order (a sorted space like the uniform
 // list's: sorted4, owned_pos = identity, row_of).
 int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
-    if (ctx->level_mode || ctx->own_flag || ctx->has_f64 || ctx->q_begin != 0 || ctx->q_end != ctx->n)
-        return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep takes whole float32 clouds");
+    if (ctx->level_mode || ctx->own_flag || ctx->q_begin != 0 || ctx->q_end != ctx->n)
+        return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep takes whole clouds");
     const int64_t n_rows = ctx->n;
     PCT_TRY(reserve_table(ctx, k, eps));
     PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
@@ -2030,12 +2035,19 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
         const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
         const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);
         const bool e = eps > 0;
-#define PCT_TREE(R_, E_, GRID_, BLOCK_) \
-    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, false, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        if (r1 && !e) PCT_TREE(1, false, grid1, block1);
-        else if (r1) PCT_TREE(1, true, grid1, block1);
-        else if (!e) PCT_TREE(2, false, grid2, block2);
-        else PCT_TREE(2, true, grid2, block2);
+        // float64 clouds: the variant whose bounds are widened by the distance between a query and its float32 rounding
+        // (Q64); where that distance is not small against the item's cells the proofs fail and the exact sweep answers
+#define PCT_TREE(R_, E_, Q_, GRID_, BLOCK_) \
+    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, Q_, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (ctx->has_f64) {
+            if (r1 && !e) PCT_TREE(1, false, true, grid1, block1);
+            else if (r1) PCT_TREE(1, true, true, grid1, block1);
+            else if (!e) PCT_TREE(2, false, true, grid2, block2);
+            else PCT_TREE(2, true, true, grid2, block2);
+        } else if (r1 && !e) PCT_TREE(1, false, false, grid1, block1);
+        else if (r1) PCT_TREE(1, true, false, grid1, block1);
+        else if (!e) PCT_TREE(2, false, false, grid2, block2);
+        else PCT_TREE(2, true, false, grid2, block2);
 #undef PCT_TREE
         PCT_HIP(ctx, hipGetLastError());
     }

@@ -60,11 +60,13 @@ __global__ __launch_bounds__(256) void k_tree_codes(const float4* __restrict__ p
 }
 
 __global__ __launch_bounds__(256) void k_tree_gather(const float4* __restrict__ pts, const unsigned* __restrict__ vals, int64_t n,
-                                                     float4* __restrict__ sorted4, int* __restrict__ owned_pos, int* __restrict__ row_of) {
+                                                     float4* __restrict__ sorted4, int* __restrict__ owned_pos, int* __restrict__ row_of,
+                                                     const double4* __restrict__ ptsd, double4* __restrict__ sorted4d) {
     const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (j >= n) return;
     const unsigned v = vals[j];
     sorted4[j] = pts[v];
+    if (ptsd) sorted4d[j] = ptsd[v];    // float64 clouds: the native coordinates travel with the float32-rounded ones
     owned_pos[j] = (int)j;              // table row = Morton position
     row_of[v] = (int)j;                 // (pts is in public order: v is the public index)
 }
@@ -315,6 +317,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, nn * sizeof(float4)));
     PCT_TRY(pct_reserve(ctx, &ctx->owned_pos, nn * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->row_of, (nn + 1) * sizeof(int)));
+    if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, nn * sizeof(double4)));
     PCT_TRY(pct_reserve(ctx, &ctx->occ, (2 * nn + 16) * sizeof(int2)));          // items; refinement appends (<= one per point)
     PCT_TRY(pct_reserve(ctx, &ctx->tree_range, (nn + 1) * (sizeof(int2) + sizeof(int)) + 64));
     u64* codes_in = (u64*)ctx->tree_codes.p;
@@ -349,7 +352,8 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_HIP(ctx, rocprim::radix_sort_pairs(ctx->tree_tmp.p, tmp_sort, codes_in, codes, vals_in, vals, nn, 0, 3 * kTreeBits, ctx->stream));
     tick(1);
     hipLaunchKernelGGL(k_tree_gather, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, (const unsigned*)vals, n,
-                       (float4*)ctx->sorted4.p, (int*)ctx->owned_pos.p, (int*)ctx->row_of.p);
+                       (float4*)ctx->sorted4.p, (int*)ctx->owned_pos.p, (int*)ctx->row_of.p,
+                       ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr, ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
     hipLaunchKernelGGL(k_tree_level, grid1, block, 0, ctx->stream, (const u64*)codes, n, n_min, max_level, (unsigned char*)ctx->tree_lvl.p);
     hipLaunchKernelGGL(k_tree_heads, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p, n, head);
     PCT_HIP(ctx, hipGetLastError());

@@ -1033,7 +1033,9 @@ def test_hierarchical_cell_list_on_awkward_clouds(gpu, monkeypatch):
     point identical (one Morton code: the level cannot go below 0), a line (one non-empty stencil cell in three), the
     reference's theta x phi lattice (equal keys everywhere), a lone point far from everything (its own cell is empty
     at every level: found by the 10:1 density probe, where one such query scanned the whole cloud), k up to 127 and
-    the eps bound; and its exact sweep alone (PCT_TREE_EXACT_ONLY) on one of them."""
+    the eps bound, float64 clouds (native queries against float32-rounded candidates; far from the origin the rounding
+    distance is no longer small against the cells and most queries end in the exact sweep); and its exact sweep alone
+    (PCT_TREE_EXACT_ONLY) on one of them."""
     capi, shapes = gpu["capi"], gpu["shapes"]
     rng = np.random.default_rng(77)
     plane = np.concatenate([rng.uniform(-1, 0, (60_000, 2)), rng.uniform(0, 1, (6_000, 2))])
@@ -1050,6 +1052,8 @@ def test_hierarchical_cell_list_on_awkward_clouds(gpu, monkeypatch):
         ("two densities, k=127", two, 127, 0.0),
         ("two densities, eps", two, 40, 0.02),
         ("torus, eps smaller than the spacing", shapes.torus_random(20_000, seed=3), 10, 0.004),
+        ("two densities, float64", two.astype(np.float64) + rng.normal(scale=1e-9, size=two.shape), 50, 0.0),
+        ("float64 far from the origin", shapes.torus_random(30_000, seed=5).astype(np.float64) * 3.0 + 4000.0, 30, 0.0),
     ]
     for name, pts, k, eps in cases:
         n = len(pts)
