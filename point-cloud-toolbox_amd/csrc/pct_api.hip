@@ -257,7 +257,16 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
     if (grid) {
-        PCT_TRY(pct_build_grid(ctx, k, eps));
+        ctx->grid_skewed = false;
+        ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 65536 && !getenv("PCT_NO_TREE") && !getenv("PCT_NO_AUTO_LEVELS");
+        const int bst = pct_build_grid(ctx, k, eps);
+        ctx->auto_probe = false;
+        PCT_TRY(bst);
+        if (ctx->grid_skewed) {                    // the uniform list was not built: far too many cells per point
+            ctx->grid_skewed = false;
+            ctx->auto_tree_n = ctx->n;
+            return run_tree();
+        }
         // PCT_KNN_AUTO on a whole cloud: is one cell size enough?  A point of a cloud of even density shares its cell
         // with about as many points as a non-empty cell holds on average; where the density spans decades the first
         // figure (size-biased) runs away from the second.  Only then the work items are counted: the share of queries

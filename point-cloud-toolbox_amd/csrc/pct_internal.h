@@ -87,6 +87,8 @@ struct pct_ctx {
     pct_buf dens_buf;               // float2 (n): log2 of the largest edge known too small / the smallest known too large
     pct_buf pub_pos, pub_dist, pub_cnt;   // public-space neighbour table the passes are merged into
     bool uneven = false;
+    bool auto_probe = false;        // PCT_KNN_AUTO on a cloud the hierarchical list could take: pct_build_grid gives up (grid_skewed)
+    bool grid_skewed = false;       // rather than build a uniform list of more than 16 cells per point
     int64_t auto_tree_n = 0;        // PCT_KNN_AUTO sent a cloud of this size to the hierarchical list: the next one of the same
     int32_t auto_tree_calls = 0;    // size goes there directly (no uniform build first); re-examined every 16th call
     bool last_levels = false;       // the table in place came from pct_knn_levels            // a plain grid sweep of this cloud left > 5 % of the queries to the exact kernel
