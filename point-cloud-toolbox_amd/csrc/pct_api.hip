@@ -259,6 +259,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     if (grid) {
         ctx->grid_skewed = false;
         ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 65536 && !getenv("PCT_NO_TREE") && !getenv("PCT_NO_AUTO_LEVELS");
+        ctx->auto_probe_tree = ctx->auto_probe;
         const int bst = pct_build_grid(ctx, k, eps);
         ctx->auto_probe = false;
         PCT_TRY(bst);
@@ -277,8 +278,9 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
             ctx->nonempty_cells > 0 && !getenv("PCT_NO_AUTO_LEVELS")) {
             const double skew = ctx->tm.occupancy * (double)ctx->nonempty_cells / (double)ctx->n;
             if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] occupancy %.1f, %lld non-empty cells, skew %.2f\n", ctx->tm.occupancy, (long long)ctx->nonempty_cells, skew);
-            if (!(skew > 1.5)) ctx->auto_tree_n = 0;
-            if (skew > 1.5) {
+            const double skew_min = ctx->auto_probe_tree ? 1.25 : 1.5;      // (the chain needs a wider spread to pay)
+            if (!(skew > skew_min)) ctx->auto_tree_n = 0;
+            if (skew > skew_min) {
                 unsigned long long c[4];
                 PCT_TRY(pct_item_census(ctx, k, c));
                 const double q = (double)(c[0] ? c[0] : 1), fail = (double)(c[1] + c[2]) / q, fine = (double)c[0] - (double)(c[1] + c[2]);
@@ -286,8 +288,8 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
                 // (the hierarchical list costs ~1.7x a uniform one whatever the density; every query the uniform list
                 // would hand to the exact sweep costs about as much as twelve it answers itself)
-                if (tree_ok && !getenv("PCT_NO_TREE") ? fail > 0.12 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
-                    if (tree_ok && !getenv("PCT_NO_TREE")) { ctx->auto_tree_n = ctx->n; return run_tree(); }
+                if (ctx->auto_probe_tree ? fail > 0.08 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
+                    if (ctx->auto_probe_tree) { ctx->auto_tree_n = ctx->n; return run_tree(); }
                     return run_levels();
                 }
                 ctx->auto_tree_n = 0;

@@ -88,6 +88,7 @@ struct pct_ctx {
     pct_buf pub_pos, pub_dist, pub_cnt;   // public-space neighbour table the passes are merged into
     bool uneven = false;
     bool auto_probe = false;        // PCT_KNN_AUTO on a cloud the hierarchical list could take: pct_build_grid gives up (grid_skewed)
+    bool auto_probe_tree = false;   // ... and the census that follows may send the call there
     bool grid_skewed = false;       // rather than build a uniform list of more than 16 cells per point
     int64_t auto_tree_n = 0;        // PCT_KNN_AUTO sent a cloud of this size to the hierarchical list: the next one of the same
     int32_t auto_tree_calls = 0;    // size goes there directly (no uniform build first); re-examined every 16th call
