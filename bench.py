@@ -27,6 +27,7 @@ import time
 import numpy as np
 
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")      # glibc's fatal diagnostics to stderr, not to the terminal
+os.environ.setdefault("PCT_ABORT_TRACE", "1")          # a bare abort() anywhere: native backtrace of the raising thread first
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes: the host driver supports dmabuf IPC only
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -2,9 +2,14 @@
 // only: buffer ownership, launch order, hipEvent timing, status mapping.
 #include "pct_internal.h"
 
+#include <execinfo.h>
 #include <math.h>
+#include <mutex>
+#include <signal.h>
 #include <stdarg.h>
 #include <stdlib.h>
+#include <sys/prctl.h>
+#include <unistd.h>
 
 int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...) {
     if (ctx) {
@@ -59,9 +64,47 @@ int pct_device_count(int* count) {
     return e == hipSuccess ? PCT_OK : PCT_ERR_NO_DEVICE;
 }
 
+// PCT_ABORT_TRACE=1: a SIGABRT anywhere in the process first writes the NATIVE backtrace and the name of the thread
+// that raised it to stderr, then goes on to whoever handled the signal before (Python's fault handler, the default
+// action).  Twice in two rounds a GPU test run died with nothing but "Fatal Python error: Aborted" in its log -- no
+// GPU fault line, no glibc diagnostic: the raiser is some library's bare abort(), possibly on a runtime
+// helper thread that a Python traceback cannot show.  Tests, bench.py and smoke() switch this on.
+static struct sigaction g_prev_abrt;
+static void abort_trace(int) {
+    static const char head[] = "\n[pct] SIGABRT -- native backtrace of the raising thread";
+    (void)!write(2, head, sizeof(head) - 1);
+    char name[32] = {0};
+    if (prctl(PR_GET_NAME, name, 0, 0, 0) == 0) {
+        (void)!write(2, " (", 2);
+        (void)!write(2, name, strnlen(name, sizeof(name)));
+        (void)!write(2, ")", 1);
+    }
+    (void)!write(2, ":\n", 2);
+    void* frames[64];
+    const int n = backtrace(frames, 64);
+    backtrace_symbols_fd(frames, n, 2);
+    sigaction(SIGABRT, &g_prev_abrt, nullptr);
+    raise(SIGABRT);
+}
+static void install_abort_trace() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        if (!getenv("PCT_ABORT_TRACE")) return;
+        void* warm[4];
+        (void)backtrace(warm, 4);                 // loads the unwinder now, not inside the handler
+        struct sigaction sa;
+        memset(&sa, 0, sizeof(sa));
+        sa.sa_handler = abort_trace;
+        sigemptyset(&sa.sa_mask);
+        sa.sa_flags = SA_NODEFER;
+        sigaction(SIGABRT, &sa, &g_prev_abrt);
+    });
+}
+
 int pct_create(int device, pct_ctx** out) {
     if (!out) return PCT_ERR_INVALID;
     *out = nullptr;
+    install_abort_trace();
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device < 0 || device >= n) return PCT_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return PCT_ERR_NO_DEVICE;

@@ -14,6 +14,9 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # glibc writes its fatal diagnostics ("free(): invalid pointer", "malloc(): corrupted top size", stack smashing ...) to
 # the controlling TERMINAL unless told otherwise -- on a GPU box they vanish and all a log shows is "Aborted".
 os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+# ... and a bare abort() in some library says nothing at all: libpct_hip.so then writes the native backtrace of the
+# raising thread before Python's fault handler gets the signal (pct_api.hip: install_abort_trace).
+os.environ.setdefault("PCT_ABORT_TRACE", "1")
 
 
 def pytest_configure(config):
