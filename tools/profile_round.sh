@@ -20,6 +20,10 @@ echo sq2 done
 # the reference's own lattice torus (utils.py:883), same step
 PCT_PROBE_NO_STATS=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat -- python3 tools/lattice_probe.py 1000 50 "torus grid" > $O/lattice.log 2>&1
 echo lattice done
+# the hierarchical cell list on a 1/r^2 scan (what PCT_KNN_AUTO takes for it)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/tree -- python3 tools/tree_probe.py 1000000 40 > $O/tree.log 2>&1
+echo tree done
+find $O/tree -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/tree_kernel_stats.csv
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 find $O/lat -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/lattice_kernel_stats.csv
 python tools/pmc_summary.py $O/sq1 $O/sq2 > $O/sq.json
