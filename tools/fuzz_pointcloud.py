@@ -46,7 +46,7 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
         if op == "plant":
             k = min(int(rng.choice([10, 15, 30, 50, 70])), n - 1)     # (k = 6 is an exactly determined fit: its agreement with
                                                                        # the oracle's SVD solve is a matter of conditioning, not of state)
-            pc.plant_kdtree(k, algorithm=str(rng.choice(["auto", "grid", "brute"])))
+            pc.plant_kdtree(k, algorithm=str(rng.choice(["auto", "grid", "brute", "tree"])))
             planted = k
             if pc.k_neighbors != k: bad = "k_neighbors not overwritten (Q15)"
         elif op == "idx":

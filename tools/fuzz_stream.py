@@ -54,8 +54,10 @@ def run(seed0=0, budget=None, cases=None, verbose=True):
         else:
             h.set_points(pts)
         h.set_query_range(lo, hi)
-        h.curvature(k, eps, _capi.KNN_GRID)
-        if verbose: print("   grid sweep done", flush=True)
+        # one handle, every structure in turn: uniform list, hierarchical list (a shard asked of it: the chain), the default's choice
+        algo = int(rng.choice([_capi.KNN_GRID, _capi.KNN_GRID, _capi.KNN_TREE, _capi.KNN_AUTO]))
+        h.curvature(k, eps, algo)
+        if verbose: print(f"   sweep done (asked {algo}, ran {h.timings()['algo']})", flush=True)
         got = h.get_neighbors(lo, hi, want_count=True) + h.get_fit(lo, hi)[:3]
         f = _capi.Handle(0); f.set_points(pts); f.set_query_range(lo, hi); f.curvature(k, eps, _capi.KNN_BRUTE)
         want = f.get_neighbors(lo, hi, want_count=True) + f.get_fit(lo, hi)[:3]
