@@ -1,4 +1,4 @@
-"""Large random clouds: the fast sweep (+ redo) against the all-exact sweep of the same cell list, sharded too
+"""Large random clouds: the fast sweep (+ redo) and the hierarchical cell list against the all-exact sweep of the uniform cell list, sharded too
 (developer tool).  python tools/fuzz_big.py [seconds] [seed]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -54,6 +54,14 @@ def run(seed0, budget=None, cases=None, verbose=True, n_max_log10=6.3):
         cfg, Kg, Hg, _ = h.get_fit(0, n)
         ok = (np.array_equal(ie, ig) and np.array_equal(de, dg) and np.array_equal(ce, cg) and np.array_equal(cfe, cfg, equal_nan=True)
               and np.array_equal(Ke, Kg, equal_nan=True) and np.array_equal(He, Hg, equal_nan=True))
+        # the hierarchical cell list (and, for what it declines, the chain) over the same cloud
+        h.curvature(k, eps, _capi.KNN_TREE)
+        tt = h.timings()
+        it3, dt3, ct3 = h.get_neighbors(0, n, want_count=True)
+        cft, Kt, Ht, _ = h.get_fit(0, n)
+        ok = ok and (np.array_equal(ie, it3) and np.array_equal(de, dt3) and np.array_equal(ce, ct3) and np.array_equal(cfe, cft, equal_nan=True)
+                     and np.array_equal(Ke, Kt, equal_nan=True) and np.array_equal(He, Ht, equal_nan=True))
+        if verbose: print(f"   tree step {tt['total_ms']:.2f} ms (ran {tt['algo']})", flush=True)
         lo = int(rng.integers(0, n - 1)); hi = int(rng.integers(lo + 1, n + 1))
         h.set_query_range(lo, hi)
         h.curvature(k, eps, _capi.KNN_GRID)
