@@ -70,26 +70,33 @@ int pct_device_count(int* count) {
 // GPU fault line, no glibc diagnostic: the raiser is some library's bare abort(), possibly on a runtime
 // helper thread that a Python traceback cannot show.  Tests, bench.py and smoke() switch this on.
 static struct sigaction g_prev_abrt;
+static int g_abrt_fd = 2;       // PCT_ABORT_TRACE=<fd>: a descriptor of the REAL stderr (a test runner that captures fd 2
+                                // -- pytest -- would swallow the trace with the dying process; tests/conftest.py dups it
+                                // before capturing starts)
 static void abort_trace(int) {
     static const char head[] = "\n[pct] SIGABRT -- native backtrace of the raising thread";
-    (void)!write(2, head, sizeof(head) - 1);
+    const int fd = g_abrt_fd;
+    (void)!write(fd, head, sizeof(head) - 1);
     char name[32] = {0};
     if (prctl(PR_GET_NAME, name, 0, 0, 0) == 0) {
-        (void)!write(2, " (", 2);
-        (void)!write(2, name, strnlen(name, sizeof(name)));
-        (void)!write(2, ")", 1);
+        (void)!write(fd, " (", 2);
+        (void)!write(fd, name, strnlen(name, sizeof(name)));
+        (void)!write(fd, ")", 1);
     }
-    (void)!write(2, ":\n", 2);
+    (void)!write(fd, ":\n", 2);
     void* frames[64];
     const int n = backtrace(frames, 64);
-    backtrace_symbols_fd(frames, n, 2);
+    backtrace_symbols_fd(frames, n, fd);
     sigaction(SIGABRT, &g_prev_abrt, nullptr);
     raise(SIGABRT);
 }
 static void install_abort_trace() {
     static std::once_flag once;
     std::call_once(once, [] {
-        if (!getenv("PCT_ABORT_TRACE")) return;
+        const char* e = getenv("PCT_ABORT_TRACE");
+        if (!e) return;
+        const int fd = atoi(e);
+        if (fd > 2) g_abrt_fd = fd;
         void* warm[4];
         (void)backtrace(warm, 4);                 // loads the unwinder now, not inside the handler
         struct sigaction sa;

@@ -21,6 +21,12 @@ os.environ.setdefault("PCT_ABORT_TRACE", "1")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # capturing is suspended while the session is configured: fd 2 is the real stderr here.  The library writes the
+    # backtrace of an abort() to this copy -- what it writes to fd 2 during a test dies with pytest's capture file.
+    try:
+        os.environ["PCT_ABORT_TRACE"] = str(os.dup(2))
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")
