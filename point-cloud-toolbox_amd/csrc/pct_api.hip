@@ -69,6 +69,7 @@ int pct_device_count(int* count) {
 // action).  Twice in two rounds a GPU test run died with nothing but "Fatal Python error: Aborted" in its log -- no
 // GPU fault line, no glibc diagnostic: the raiser is some library's bare abort(), possibly on a runtime
 // helper thread that a Python traceback cannot show.  Tests, bench.py and smoke() switch this on.
+extern "C++" { const char* volatile pct_last_launch = "(none)"; }
 static struct sigaction g_prev_abrt;
 static int g_abrt_fd = 2;       // PCT_ABORT_TRACE=<fd>: a descriptor of the REAL stderr (a test runner that captures fd 2
                                 // -- pytest -- would swallow the trace with the dying process; tests/conftest.py dups it
@@ -84,6 +85,11 @@ static void abort_trace(int) {
         (void)!write(fd, ")", 1);
     }
     (void)!write(fd, ":\n", 2);
+    static const char last[] = "[pct] last kernel launched by the library: ";
+    (void)!write(fd, last, sizeof(last) - 1);
+    const char* ll = pct_last_launch;
+    (void)!write(fd, ll, strlen(ll));
+    (void)!write(fd, "\n", 1);
     void* frames[64];
     const int n = backtrace(frames, 64);
     backtrace_symbols_fd(frames, n, fd);

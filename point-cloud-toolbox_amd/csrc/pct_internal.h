@@ -11,6 +11,19 @@
 
 #define PCT_WAVE 64
 
+// Every kernel launch of the library leaves its source position and kernel name here; the abort hook
+// (pct_api.hip: install_abort_trace) prints it, so that the log of a GPU memory fault -- ROCr aborts the process from
+// its own thread -- names the launch that preceded it (exactly the faulting one under HIP_LAUNCH_BLOCKING=1).
+extern const char* volatile pct_last_launch;
+#define PCT_STR2(x) #x
+#define PCT_STR(x) PCT_STR2(x)
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                                  \
+    do {                                                                                     \
+        pct_last_launch = __FILE__ ":" PCT_STR(__LINE__) "  " #kernelName;                   \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                               \
+    } while (0)
+
 // ---------------------------------------------------------------------------
 // Uniform cell list over the float32-rounded cloud.
 // Cell id = (cz * ny + cy) * nx + cx; cell coordinates are computed in fp64 so

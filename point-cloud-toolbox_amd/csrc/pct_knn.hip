@@ -266,7 +266,13 @@ struct Sweep {
     __device__ __forceinline__ void consider(float4 c, int pos, bool valid) {
         const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
         const double d2 = (dx * dx + dy * dy) + dz * dz;
-        const bool closer = key_less(d2, pos, tau_d, tau_p, pts);   // every lane takes part (wave ballot inside)
+        // Every lane takes part (wave ballot inside) -- but a lane without a candidate must not take part in the
+        // tie-break: its registers hold the coordinates of an EARLIER batch (or zeros), whose d2 can equal the running
+        // (k+1)-th distance exactly (that earlier candidate may BE the (k+1)-th), and the tie-break reads the public
+        // index at `pos` -- up to 63 records past the end of the cloud for the last batch of the last run.  On clouds
+        // below ~380 points that is beyond the head-room of the allocation: the GPU memory fault that aborted a test
+        // run once in a while for two rounds.  The padding position never enters a tie-break.
+        const bool closer = key_less(d2, valid ? pos : INT_MAX, tau_d, tau_p, pts);
         const bool pass = valid && d2 < eps2 && closer;
         const unsigned long long m = __ballot(pass);
         if (pass) {

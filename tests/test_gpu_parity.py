@@ -1080,6 +1080,36 @@ def test_hierarchical_cell_list_on_awkward_clouds(gpu, monkeypatch):
         h.close()
 
 
+def test_exact_sweeps_on_tiny_clouds_whose_last_batch_is_mostly_empty(gpu):
+    """The scenario behind the GPU memory fault that aborted a suite run now and then for two rounds (found at last by
+    `tools/fuzz_tiny.py` seed 13, case 244: n=198, k=96, every query through `k_knn_exact<2>`): the last 64-candidate
+    batch of a run has lanes without a candidate, their registers hold an earlier candidate (or zeros) whose squared
+    distance ties with the running (k+1)-th EXACTLY, and the tie-break looked up the public index at a position up to
+    63 records past the end of the cloud.  The read never changed a value -- such lanes cannot pass -- but on clouds
+    this small it left the allocation.  A cloud at the origin makes every empty lane tie (d2 = 0 = tau); the fuzz case
+    is replayed as generated.  Values against the exhaustive sweep / the oracle."""
+    capi = gpu["capi"]
+    rng = np.random.default_rng([13, 244])
+    n = int(rng.integers(2, 300)); k = int(rng.integers(1, min(127, n - 1) + 1)); kind = rng.integers(0, 4)
+    assert (n, k, int(kind)) == (198, 96, 0)
+    clouds = [(rng.normal(size=(n, 3)).astype(np.float32), k), (np.zeros((100, 3), np.float32), 20), (np.zeros((65, 3), np.float32), 63),
+              (np.concatenate([np.zeros((40, 3)), rng.normal(size=(30, 3))]).astype(np.float32), 33)]
+    for pts, kk in clouds:
+        m = len(pts)
+        h = capi.Handle(0)
+        h.set_points(pts)
+        h.knn(kk, algo=capi.KNN_BRUTE)
+        ib, db, _ = h.get_neighbors(0, m)
+        assert np.array_equal(db, oracle.knn(pts, kk)[1])              # (indices: exact ties are ordered by index here)
+        for algo in (capi.KNN_GRID_EXACT, capi.KNN_GRID, capi.KNN_TREE):
+            h.knn(kk, algo=algo)
+            ig, dg, _ = h.get_neighbors(0, m)
+            assert np.array_equal(ib, ig) and np.array_equal(db, dg), (m, kk, algo)
+        idx, dist = h.query_points(pts[:5].astype(np.float64), kk)
+        assert np.array_equal(dist[:, 1:].astype(np.float32), db[:5, :kk - 1])
+        h.close()
+
+
 def test_chain_window_and_histogram_agree_at_a_bin_boundary(gpu):
     """Found by tools/fuzz_gpu.py (seed 31, case 5827): a float64 cloud far from the origin, quantised by float32 into
     piles of identical points -- every pending query of the chained sweep wanted exactly the edge of a histogram bin

@@ -27,6 +27,8 @@ def run(seed0=9, budget=None, cases=None):
         h.curvature(k, eps, _capi.KNN_BRUTE)
         ib, db, cb = h.get_neighbors(0, n, want_count=True); cfb, Kb, Hb, _ = h.get_fit(0, n)
         for algo in (_capi.KNN_GRID, _capi.KNN_GRID_LEVELS, _capi.KNN_GRID_EXACT, _capi.KNN_TREE):
+            if os.environ.get("FUZZ_TINY_VERBOSE"):
+                print(f"tiny case ({seed0},{it}): n={n} k={k} kind={kind} eps={eps} dtype={pts.dtype} algo={algo}", file=sys.stderr, flush=True)
             h.curvature(k, eps, algo)
             ig, dg, cg = h.get_neighbors(0, n, want_count=True); cfg, Kg, Hg, _ = h.get_fit(0, n)
             if not (np.array_equal(ib, ig) and np.array_equal(db, dg) and np.array_equal(cb, cg) and np.array_equal(cfb, cfg, equal_nan=True)
