@@ -21,16 +21,23 @@ int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+void pct_release(pct_buf* b) {
+    if (b->p) (void)hipFree(b->p);
+    b->p = nullptr;
+    b->cap = 0;
+}
+
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes) {
     if (bytes == 0) bytes = 16;
     if (b->cap >= bytes) return PCT_OK;
     if (b->p) {
         PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        PCT_HIP(ctx, hipFree(b->p));
-        b->p = nullptr;
-        b->cap = 0;
+        pct_release(b);
     }
     size_t want = bytes + bytes / 8 + 256;   // a little head-room for repeated calls with growing sizes
+    // (debugging: exact sizes -- every growing request moves the buffer, so code that keeps a pointer across a
+    // reserve, or counts on the spare bytes behind a buffer, shows)
+    if (getenv("PCT_NO_HEADROOM")) want = bytes;
     hipError_t e = hipMalloc(&b->p, want);
     if (e != hipSuccess) {
         b->p = nullptr;
@@ -40,11 +47,7 @@ int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes) {
     return PCT_OK;
 }
 
-static void release(pct_buf* b) {
-    if (b->p) (void)hipFree(b->p);
-    b->p = nullptr;
-    b->cap = 0;
-}
+static void release(pct_buf* b) { pct_release(b); }
 
 static float ev_ms(pct_ctx* ctx, int a, int b) {
     float ms = 0.f;

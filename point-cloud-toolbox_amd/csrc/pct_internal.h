@@ -198,6 +198,7 @@ inline double pct_default_factor(int k) {
     return n <= 85 ? 0.52 : n <= 101 ? 0.52 - 0.07 * (n - 85) / 16.0 : 0.45 - 0.05 * (n - 101) / 27.0;
 }
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);
+void pct_release(pct_buf* b);
 
 // Morton codes of the hierarchical cell list: 21 bits per axis, x in bit 0 of every triple
 __host__ __device__ inline unsigned long long pct_spread3(unsigned v) {         // bit i -> bit 3 i

@@ -397,7 +397,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
             PCT_TRY(pct_reserve(ctx, &bigger, room * 27 * sizeof(int2)));
             PCT_HIP(ctx, hipMemcpyAsync(bigger.p, ctx->tree_runs.p, (size_t)n_segs * 27 * sizeof(int2), hipMemcpyDeviceToDevice, ctx->stream));
             PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
-            (void)hipFree(ctx->tree_runs.p);
+            pct_release(&ctx->tree_runs);
             ctx->tree_runs = bigger;
         }
         const int64_t waves = bad_segs < 16384 ? n_segs : n_segs;
