@@ -41,6 +41,9 @@ constexpr int PCT_STAGE_CAP2_HOST = PCT_STAGE_CAP2;
 #ifndef PCT_TREE_CAP
 #define PCT_TREE_CAP 768                   // staged candidates of a work item of the hierarchical cell list (A/B: 512 | 768 | 1024)
 #endif
+#ifndef PCT_TREE_CAP2
+#define PCT_TREE_CAP2 1024                 // ... for k + 1 > 64 (two list registers): the proofs want ~2.6 (k+1) stencil points
+#endif
 
 struct KnnArgs {
     const float4* pts;        // candidate records {x,y,z,public index}; cell-sorted (grid) or public order (brute)
@@ -803,7 +806,7 @@ typedef float float2v __attribute__((ext_vector_type(2)));
 // PAIR (with PRE, R = 1): two queries of the item per loop trip, their instruction streams side by side in the same
 // basic blocks -- they share the LDS reads of the candidates, and each hides the other's dependency stalls.
 template <int R, bool EPS, bool PRE, bool PAIR = false, bool Q64 = false, bool TREE = false>
-__global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? (PCT_TREE_CAP <= 512 && R == 1 ? 6 : PCT_TREE_CAP <= 768 ? 4 : 3) : R == 1 ? (Q64 ? 5 : 6) : 4)) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
+__global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? (R == 1 ? (PCT_TREE_CAP <= 512 ? 6 : PCT_TREE_CAP <= 768 ? 4 : 3) : (PCT_TREE_CAP2 <= 768 ? 4 : 3)) : R == 1 ? (Q64 ? 5 : 6) : 4)) void k_knn_fast(KnnArgs a, const int2* __restrict__ items, int64_t n_items,
                                                                   int items_q, int* __restrict__ redo,
                                                                   int* __restrict__ redo_count) {
 #ifndef PCT_STAGE_CAP2
@@ -813,7 +816,7 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? (PCT_TREE_CAP <= 512 &&
     // staging area are split further at build time (k_tree_refine), so the capacity trades refinement and trips to
     // the exact sweep against occupancy: 768 slots / 4 blocks per CU measured best -- 1/r^2 scan, 1 M points: fast
     // sweep 0.51 | 0.65 | 0.83 ms at 512 | 768 | 1024 slots, whole call 2.30 | 1.57 | 1.65 ms)
-    constexpr int CAP = TREE ? PCT_TREE_CAP : R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
+    constexpr int CAP = TREE ? (R == 1 ? PCT_TREE_CAP : PCT_TREE_CAP2) : R == 1 ? kStageCap : PCT_STAGE_CAP2;   // staged stencil candidates per wave
     // low bits of a network element: the staged slot of the candidate, or -- pre-selection -- its place in the
     // compacted list of survivors (6 / 7 bits; the slot is looked up in that list afterwards), which leaves three
     // more bits for the key and cuts key collisions eightfold

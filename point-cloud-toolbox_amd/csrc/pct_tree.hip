@@ -379,7 +379,10 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
 #ifndef PCT_TREE_CAP
 #define PCT_TREE_CAP 768
 #endif
-    int cap = PCT_TREE_CAP;
+#ifndef PCT_TREE_CAP2
+#define PCT_TREE_CAP2 1024
+#endif
+    int cap = k + 1 <= pct_fast_r1_max() ? PCT_TREE_CAP : PCT_TREE_CAP2;
     if (const char* e = getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
     size_t room = (size_t)n_segs + nn / 8 + 64;           // segments the range table has room for
     PCT_TRY(pct_reserve(ctx, &ctx->tree_runs, room * 27 * sizeof(int2)));
