@@ -971,6 +971,68 @@ def test_rccl_exchange_of_unequal_shards_in_process(gpu):
     h.close()
 
 
+def test_sharded_driver_on_four_handles_with_a_loopback_exchange(gpu):
+    """What a 4-GPU job does, on one GPU: four handles, each driven by its own ShardedCurvature (rank r of 4, unequal
+    shards -- n is not a multiple of 4), through the DEVICE path of the driver (send buffer, two gather buffers, cloud
+    read in place, owned range, culling of the far points); the exchange is an in-process stand-in that moves the
+    shards between the handles' buffers the way the all-gather does (RCCL refuses two ranks on one device; the
+    communicator itself is covered above with one rank and on the driver's 8-GPU node).  Two clouds through the same
+    drivers, so that both gather buffers are used.  Rows against the plain whole-cloud handle, bit for bit."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    from point_cloud_toolbox_amd.dist import ShardedCurvature, shard_range
+    world, n, k = 4, 120_003, 30
+
+    class RankHandle(capi.Handle):
+        def comm_synchronize(self):                   # no exchange stream here: the copies below are blocking
+            self.synchronize()
+
+    class Loopback:
+        def __init__(self, hub, rank):
+            self.hub, self.rank = hub, rank
+
+        def begin(self, send, recv, counts):
+            self.hub[self.rank] = (send, recv, [int(c) for c in counts])
+            return self.rank
+
+        def end(self, rank):
+            _, recv, counts = self.hub[rank]
+            off = 0
+            for src in range(world):
+                s_ptr = self.hub[src][0]
+                host = np.empty(counts[src], np.float32)
+                handles[src].device_download(s_ptr, host)
+                handles[rank].device_upload(recv + 4 * off, host)
+                off += counts[src]
+            return recv
+
+    handles = [RankHandle(0) for _ in range(world)]
+    hub = {}
+    drivers = [ShardedCurvature(n, k, r, world, handle=handles[r], exchange=Loopback(hub, r)) for r in range(world)]
+    ref = capi.Handle(0)
+    for step, seed in enumerate((31, 32)):
+        parts = [shapes.torus_scan_order(n, world, r, seed=seed) for r in range(world)]
+        for r in range(world):
+            lo, hi = shard_range(n, r, world)
+            assert len(parts[r]) == hi - lo
+            drivers[r].upload_shard(parts[r])
+        tickets = [drivers[r].begin_exchange(step) for r in range(world)]
+        got_K, got_H = [], []
+        for r in range(world):
+            drivers[r].run_device(drivers[r].end_exchange(tickets[r]))
+            K, H = drivers[r].download()
+            got_K.append(K)
+            got_H.append(H)
+            assert handles[r].timings()["grid_points"] < n            # the far three quarters were left out of the cell list
+        ref.set_points(np.concatenate(parts))
+        ref.curvature(k, 0.0, capi.KNN_GRID)
+        _, K0, H0, _ = ref.get_fit(0, n, coefs=False, H2=False)
+        assert np.array_equal(np.concatenate(got_K), K0) and np.array_equal(np.concatenate(got_H), H0), step
+    for d in drivers:
+        d.close()
+    for h in handles + [ref]:
+        h.close()
+
+
 @pytest.mark.parametrize("algo", ["levels", "tree"])
 @pytest.mark.parametrize("kind", ["blobs", "outliers", "shell_and_core", "quantised"])
 def test_chain_of_cell_lists_equals_exhaustive_sweep(gpu, kind, algo):
