@@ -317,7 +317,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
     if (grid) {
         ctx->grid_skewed = false;
-        ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 65536 && !getenv("PCT_NO_TREE") && !getenv("PCT_NO_AUTO_LEVELS");
+        ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 16384 && !getenv("PCT_NO_TREE") && !getenv("PCT_NO_AUTO_LEVELS");
         ctx->auto_probe_tree = ctx->auto_probe;
         const int bst = pct_build_grid(ctx, k, eps);
         ctx->auto_probe = false;
@@ -347,7 +347,11 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
                 // (the hierarchical list costs ~1.7x a uniform one whatever the density; every query the uniform list
                 // would hand to the exact sweep costs about as much as twelve it answers itself)
-                if (ctx->auto_probe_tree ? fail > 0.08 && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
+                // (the hierarchical list's build -- a dozen launches, three read-backs -- costs ~0.45 ms more than the
+                // uniform one whatever the cloud's size, a query handed to the exact sweep ~12 ns: below a million
+                // points the predicted share must be larger for the switch to pay)
+                const double fail_min = fmax(0.08, 37500.0 / (double)ctx->n);
+                if (ctx->auto_probe_tree ? fail > fail_min && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
                     if (ctx->auto_probe_tree) { ctx->auto_tree_n = ctx->n; return run_tree(); }
                     return run_levels();
                 }

@@ -883,7 +883,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         // PCT_KNN_AUTO: a surface wants about a third of a cell per point; an edge that asks for 16 cells per point was
         // steered there by a dense minority (the size-biased occupancy) -- a 1/r^2 scan wants 130 per point, 1.6 ms of
         // counters and scans that the hierarchical list does not need.  Nothing was built: the caller goes there.
-        if (ctx->auto_probe && !own_flag && g.ncell > 16 * n && g.ncell > ((int64_t)1 << 22)) {
+        if (ctx->auto_probe && !own_flag && g.ncell > 16 * n && g.ncell > ((int64_t)1 << 20)) {
             ctx->grid_skewed = true;
             ctx->grid_valid = false;
             return PCT_OK;
