@@ -153,7 +153,7 @@ void pct_destroy(pct_ctx* ctx) {
                       &ctx->scan_tmp, &ctx->occ, &ctx->redo, &ctx->row_of, &ctx->owned_pos, &ctx->cell_own, &ctx->cell_oth, &ctx->own_start, &ctx->sorted4, &ctx->sorted4d, &ctx->red, &ctx->nbr_pos,
                       &ctx->nbr_dist, &ctx->nbr_cnt, &ctx->counters, &ctx->coefs, &ctx->K, &ctx->H, &ctx->H2,
                       &ctx->stage_a, &ctx->stage_b, &ctx->stage_c, &ctx->stage_d, &ctx->row_done, &ctx->redo_m, &ctx->flag_buf, &ctx->dens_buf, &ctx->pub_pos, &ctx->pub_dist, &ctx->pub_cnt, &ctx->qpts4, &ctx->fit_flag, &ctx->lvl_src,
-                      &ctx->tree_codes, &ctx->tree_vals, &ctx->tree_lvl, &ctx->tree_head, &ctx->tree_marks, &ctx->tree_seg, &ctx->tree_runs, &ctx->tree_range, &ctx->tree_tmp};
+                      &ctx->tree_codes, &ctx->tree_vals, &ctx->tree_lvl, &ctx->tree_head, &ctx->tree_marks, &ctx->tree_seg, &ctx->tree_runs, &ctx->tree_range, &ctx->tree_bucket, &ctx->tree_tmp};
     for (pct_buf* b : all) release(b);
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)

@@ -93,6 +93,7 @@ struct pct_ctx {
     pct_buf tree_head, tree_marks;  // segment / item marks and their scans
     pct_buf tree_seg, tree_runs;    // int4 per segment {level, cx, cy, cz}; int2 x 27 per segment {first position, points}
     pct_buf tree_range;             // int2 per segment {first position, points} + int per segment: stencil population + device totals
+    pct_buf tree_bucket;            // int (2^18 + 2): first position of every 18-bit code prefix (pct_code_lower_bound)
     pct_buf tree_tmp;
     pct_buf row_done;               // int32 (rows of the pass)
     pct_buf redo_m;                 // int32, parallel to redo: stencil population of the row's item
@@ -229,6 +230,20 @@ __host__ __device__ inline void pct_stencil_cell(int t, int* dx, int* dy, int* d
 // first position of the Morton-sorted code array whose code is >= key
 __device__ inline int64_t pct_code_lower_bound(const unsigned long long* __restrict__ codes, int64_t n, unsigned long long key) {
     int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (codes[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// The same through the bucket table of the tree build: bucket[p] = first position whose code >= p << kTreeBucketShift
+// (2^18 + 2 entries).  A search is a chain of dependent loads, ~20 over a million codes; the table leaves the two or
+// three inside one bucket (the refinement of a segment next to a much denser region is a chain of such searches).
+constexpr int kTreeBucketBits = 18, kTreeBucketShift = 63 - kTreeBucketBits;
+__device__ inline int64_t pct_code_lower_bound(const unsigned long long* __restrict__ codes, const int* __restrict__ bucket,
+                                               unsigned long long key) {
+    const unsigned p = (unsigned)(key >> kTreeBucketShift);
+    int64_t lo = bucket[p], hi = bucket[p + 1];
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
         if (codes[mid] < key) lo = mid + 1; else hi = mid;

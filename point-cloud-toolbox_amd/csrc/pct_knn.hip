@@ -73,6 +73,7 @@ struct KnnArgs {
     int tree_bits;            // levels below the root (cells per axis at level l: 2^(tree_bits - l)); g = the finest level's grid
     const unsigned long long* tree_codes;   // Morton code of every position (exact sweep on the tree)
     const unsigned char* tree_lvl;          // level every position is served at
+    const int* tree_bucket;                 // first position of every 18-bit code prefix
     int stats;                // collect the counters below (off by default)
     unsigned long long* counters;   // [0] ring fallbacks [1] LDS overflows [2] flushes [3] candidate steps [4] redone queries [5] queries beyond the culling limits (always counted)
 };
@@ -539,8 +540,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact_tree(KnnArgs 
                 const int x = cx + dx, y = cy + dy, z = cz + dz;
                 if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
                     const unsigned long long prefix = pct_spread3((unsigned)x) | pct_spread3((unsigned)y) << 1 | pct_spread3((unsigned)z) << 2;
-                    const int64_t lo = pct_code_lower_bound(a.tree_codes, a.n, prefix << (3 * level));
-                    const int64_t hi = pct_code_lower_bound(a.tree_codes, a.n, (prefix + 1) << (3 * level));
+                    const int64_t lo = pct_code_lower_bound(a.tree_codes, a.tree_bucket, prefix << (3 * level));
+                    const int64_t hi = pct_code_lower_bound(a.tree_codes, a.tree_bucket, (prefix + 1) << (3 * level));
                     run_s = (int)lo;
                     run_len = (int)(hi - lo);
                 }
@@ -2035,6 +2036,7 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
     a.tree_bits = ctx->tree_bits;
     a.tree_codes = (const unsigned long long*)ctx->tree_codes.p + ctx->n;     // second half: the sorted codes
     a.tree_lvl = (const unsigned char*)ctx->tree_lvl.p;
+    a.tree_bucket = (const int*)ctx->tree_bucket.p;
     int* redo_count = (int*)ctx->counters.p + 14;
     int* redo = (int*)ctx->redo.p;
     const int2* items = (const int2*)ctx->occ.p;

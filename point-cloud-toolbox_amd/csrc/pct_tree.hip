@@ -102,6 +102,13 @@ __global__ __launch_bounds__(256) void k_tree_level(const u64* __restrict__ code
     lvl[j] = (unsigned char)min(min(l, kTreeBits), max_level);
 }
 
+// bucket[p] = first position whose code is >= p << kTreeBucketShift (p = 0 .. 2^18 + 1)
+__global__ __launch_bounds__(256) void k_tree_buckets(const u64* __restrict__ codes, int64_t n, int* __restrict__ bucket) {
+    const unsigned p = blockIdx.x * 256 + threadIdx.x;
+    if (p > (1u << kTreeBucketBits) + 1u) return;
+    bucket[p] = p >= (1u << kTreeBucketBits) ? (int)n : (int)pct_code_lower_bound(codes, n, (u64)p << kTreeBucketShift);
+}
+
 // head[j] = j where a segment starts (0 elsewhere; position 0 starts one anyway): an inclusive max-scan turns it into
 // the start of the segment of every point
 __global__ __launch_bounds__(256) void k_tree_heads(const u64* __restrict__ codes, const unsigned char* __restrict__ lvl, int64_t n,
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256) void k_tree_items(const u64* __restrict__ code
 }
 
 // the 27 ranges of the stencil of cell (cx, cy, cz) of level l: lane t < 27 returns range t (centre first)
-__device__ __forceinline__ int2 stencil_range(const u64* __restrict__ codes, int64_t n, int l, int cx, int cy, int cz, int t) {
+__device__ __forceinline__ int2 stencil_range(const u64* __restrict__ codes, const int* __restrict__ bucket, int l, int cx, int cy, int cz, int t) {
     int2 r = make_int2(0, 0);
     if (t < 27) {
         const int dim = 1 << (kTreeBits - l);
@@ -175,8 +182,8 @@ __device__ __forceinline__ int2 stencil_range(const u64* __restrict__ codes, int
         const int x = cx + dx, y = cy + dy, z = cz + dz;
         if (x >= 0 && x < dim && y >= 0 && y < dim && z >= 0 && z < dim) {
             const u64 prefix = spread3((unsigned)x) | spread3((unsigned)y) << 1 | spread3((unsigned)z) << 2;
-            const int64_t lo = pct_code_lower_bound(codes, n, prefix << (3 * l));
-            const int64_t hi = pct_code_lower_bound(codes, n, (prefix + 1) << (3 * l));      // l = 21: 1 << 63, above every code
+            const int64_t lo = pct_code_lower_bound(codes, bucket, prefix << (3 * l));
+            const int64_t hi = pct_code_lower_bound(codes, bucket, (prefix + 1) << (3 * l));      // l = 21: 1 << 63, above every code
             r = make_int2((int)lo, (int)(hi - lo));
         }
     }
@@ -185,7 +192,7 @@ __device__ __forceinline__ int2 stencil_range(const u64* __restrict__ codes, int
 
 // 32 threads per segment: thread t < 27 finds the range of stencil cell t; the population of the stencil decides
 // whether the segment is fine as it is (bad[0] / bad[1]: segments / points of the segments over the cap)
-__global__ __launch_bounds__(256) void k_tree_stencil(const u64* __restrict__ codes, int64_t n, const int4* __restrict__ seg_hdr,
+__global__ __launch_bounds__(256) void k_tree_stencil(const u64* __restrict__ codes, const int* __restrict__ bucket, const int4* __restrict__ seg_hdr,
                                                       const int2* __restrict__ seg_range, int64_t n_segs, int cap,
                                                       int2* __restrict__ runs, int* __restrict__ seg_pop, int* __restrict__ bad) {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(256) void k_tree_stencil(const u64* __restrict__ co
     const int t = (int)(g & 31);
     if (seg >= n_segs) return;                        // (whole 32-thread groups leave together)
     const int4 hd = seg_hdr[seg];
-    const int2 r = stencil_range(codes, n, hd.x, hd.y, hd.z, hd.w, t);
+    const int2 r = stencil_range(codes, bucket, hd.x, hd.y, hd.z, hd.w, t);
     if (t < 27) runs[seg * 27 + t] = r;
     int pop = r.y;
     for (int o = 16; o > 0; o >>= 1) pop += __shfl_xor(pop, o, 32);
@@ -210,12 +217,14 @@ __global__ __launch_bounds__(256) void k_tree_stencil(const u64* __restrict__ co
 // the level says nothing about the neighbours) are split, octant by octant, until every piece fits: one wave per such
 // segment walks its own run of points depth first.  Pieces become new segments and items at the end of the arrays,
 // the segment's old items die (segment -1).
-__global__ __launch_bounds__(256) void k_tree_refine(const u64* __restrict__ codes, int64_t n, const u64* __restrict__ sums,
+__global__ __launch_bounds__(256) void k_tree_refine(const u64* __restrict__ codes, const int* __restrict__ bucket, const u64* __restrict__ sums,
                                                      int64_t n_segs, int cap, int items_q, int4* __restrict__ seg_hdr,
                                                      const int2* __restrict__ seg_range, const int* __restrict__ seg_pop,
                                                      int2* __restrict__ runs, int2* __restrict__ items, unsigned char* __restrict__ lvl,
                                                      int* __restrict__ counts) {
     __shared__ int4 s_stack[4][160];
+    __shared__ int2 s_runs[4][8][27];
+    __shared__ int s_pop[4][8];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int4* stack = s_stack[w];
     for (int64_t seg = (int64_t)blockIdx.x * 4 + w; seg < n_segs; seg += (int64_t)gridDim.x * 4) {
@@ -230,32 +239,44 @@ __global__ __launch_bounds__(256) void k_tree_refine(const u64* __restrict__ cod
         while (sp > 0) {
             tree_lds_sync();
             const int4 e = stack[--sp];                       // {level, first position, points}: a run inside ONE cell of that level
-            tree_lds_sync();
             const int cl = e.x - 1;                           // split it by the octants of the level below
             const u64 base = (codes[e.y] >> (3 * e.x)) << 3;
             int bound = e.y + e.z;
             if (lane == 0) bound = e.y;
             else if (lane < 8) bound = e.y + (int)pct_code_lower_bound(codes + e.y, e.z, (base + (u64)lane) << (3 * cl));
+            if (lane < 8) s_pop[w][lane] = 0;
+            tree_lds_sync();
+            // the 8 x 27 stencil ranges of the octants, 64 at a time (the binary searches are what this kernel waits for)
+            for (int idx = lane; idx < 8 * 27; idx += 64) {
+                const int c = idx / 27, t = idx - c * 27;
+                const int cs = __shfl(bound, c), ce = __shfl(bound, c + 1);
+                int2 r = make_int2(0, 0);
+                if (ce > cs) {
+                    const u64 code = codes[cs];
+                    r = stencil_range(codes, bucket, cl, (int)(compact3(code) >> cl), (int)(compact3(code >> 1) >> cl), (int)(compact3(code >> 2) >> cl), t);
+                    if (r.y > 0) atomicAdd(&s_pop[w][c], r.y);
+                }
+                s_runs[w][c][t] = r;
+            }
+            tree_lds_sync();
             for (int c = 0; c < 8; ++c) {
                 const int cs = __builtin_amdgcn_readlane(bound, c), ce = __builtin_amdgcn_readlane(bound, c + 1);
                 if (ce <= cs) continue;
-                const u64 code = codes[cs];
-                const int cx = (int)(compact3(code) >> cl), cy = (int)(compact3(code >> 1) >> cl), cz = (int)(compact3(code >> 2) >> cl);
-                const int2 r = stencil_range(codes, n, cl, cx, cy, cz, lane);
-                int pop = r.y;
-                for (int o = 32; o > 0; o >>= 1) pop += __shfl_xor(pop, o);
+                const int pop = s_pop[w][c];
                 if (pop > cap && cl > 0 && sp < 159) {
                     if (lane == 0) stack[sp] = make_int4(cl, cs, ce - cs, 0);
                     ++sp;
                     continue;
                 }
+                const u64 code = codes[cs];
+                const int cx = (int)(compact3(code) >> cl), cy = (int)(compact3(code >> 1) >> cl), cz = (int)(compact3(code >> 2) >> cl);
                 const int len = ce - cs, n_new = (len + items_q - 1) / items_q;
                 int seg_new = 0, item_new = 0;
                 if (lane == 0) { seg_new = atomicAdd(&counts[1], 1); item_new = atomicAdd(&counts[0], n_new); }
                 seg_new = __builtin_amdgcn_readfirstlane(seg_new);
                 item_new = __builtin_amdgcn_readfirstlane(item_new);
                 if (lane == 0) seg_hdr[seg_new] = make_int4(cl, cx, cy, cz);
-                if (lane < 27) runs[(int64_t)seg_new * 27 + lane] = r;
+                if (lane < 27) runs[(int64_t)seg_new * 27 + lane] = s_runs[w][c][lane];
                 for (int i = lane; i < n_new; i += 64) items[item_new + i] = make_item(cs + i * items_q, min(items_q, len - i * items_q), seg_new);
                 for (int i = lane; i < len; i += 64) lvl[cs + i] = (unsigned char)cl;
             }
@@ -312,6 +333,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_TRY(pct_reserve(ctx, &ctx->tree_codes, 2 * nn * sizeof(u64)));
     PCT_TRY(pct_reserve(ctx, &ctx->tree_vals, 2 * nn * sizeof(unsigned)));
     PCT_TRY(pct_reserve(ctx, &ctx->tree_lvl, nn));
+    PCT_TRY(pct_reserve(ctx, &ctx->tree_bucket, ((size_t)(1u << kTreeBucketBits) + 2) * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->tree_head, 2 * nn * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->tree_marks, 2 * nn * sizeof(u64)));
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, nn * sizeof(float4)));
@@ -354,6 +376,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     hipLaunchKernelGGL(k_tree_gather, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, (const unsigned*)vals, n,
                        (float4*)ctx->sorted4.p, (int*)ctx->owned_pos.p, (int*)ctx->row_of.p,
                        ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr, ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
+    hipLaunchKernelGGL(k_tree_buckets, dim3(((1u << kTreeBucketBits) + 2 + 255) / 256), block, 0, ctx->stream, (const u64*)codes, n, (int*)ctx->tree_bucket.p);
     hipLaunchKernelGGL(k_tree_level, grid1, block, 0, ctx->stream, (const u64*)codes, n, n_min, max_level, (unsigned char*)ctx->tree_lvl.p);
     hipLaunchKernelGGL(k_tree_heads, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p, n, head);
     PCT_HIP(ctx, hipGetLastError());
@@ -386,7 +409,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     if (const char* e = getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
     size_t room = (size_t)n_segs + nn / 8 + 64;           // segments the range table has room for
     PCT_TRY(pct_reserve(ctx, &ctx->tree_runs, room * 27 * sizeof(int2)));
-    hipLaunchKernelGGL(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, n,
+    hipLaunchKernelGGL(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p,
                        (const int4*)ctx->tree_seg.p, (const int2*)seg_range, n_segs, cap, (int2*)ctx->tree_runs.p, seg_pop, counts + 2);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 2208, counts, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -405,7 +428,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
         }
         const int64_t waves = bad_segs < 16384 ? n_segs : n_segs;
         const int blocks = (int)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);
-        hipLaunchKernelGGL(k_tree_refine, dim3(blocks), block, 0, ctx->stream, (const u64*)codes, n, (const u64*)sums, n_segs, cap, items_q,
+        hipLaunchKernelGGL(k_tree_refine, dim3(blocks), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p, (const u64*)sums, n_segs, cap, items_q,
                            (int4*)ctx->tree_seg.p, (const int2*)seg_range, (const int*)seg_pop, (int2*)ctx->tree_runs.p, (int2*)ctx->occ.p,
                            (unsigned char*)ctx->tree_lvl.p, counts);
         PCT_HIP(ctx, hipGetLastError());
