@@ -299,6 +299,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         ctx->last_levels = false;
         bool usable = false;
         PCT_TRY(pct_build_tree(ctx, k, eps, &usable));
+        if (!usable && ctx->tree_hint_mismatch) return PCT_OK;       // (a remembered verdict that does not fit this cloud: the caller goes on)
         if (!usable) return run_levels();          // (extents or eps outside what the float32 pre-selection can square)
         PCT_HIP(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         PCT_TRY(pct_launch_knn_tree(ctx, k, eps));
@@ -310,8 +311,18 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     if (algo == PCT_KNN_TREE) return tree_ok ? run_tree() : run_levels();
     // a handle fed a stream of similar clouds: what the census said about the last one of this size still holds
     if (auto_req && tree_ok && ctx->auto_tree_n == ctx->n && (++ctx->auto_tree_calls & 15) != 0 && !getenv("PCT_NO_TREE") &&
-        !getenv("PCT_NO_AUTO_LEVELS"))
-        return run_tree();
+        !getenv("PCT_NO_AUTO_LEVELS")) {
+        // (the verdict holds for clouds of this size AND this bounding box, within 2 % per face -- the same test the
+        // speculative cell-list build applies to "a stream of similar clouds")
+        ctx->tree_check_bbox = true;
+        ctx->tree_hint_mismatch = false;
+        const int st = run_tree();
+        ctx->tree_check_bbox = false;
+        if (!ctx->tree_hint_mismatch) return st;
+        ctx->tree_hint_mismatch = false;
+        ctx->auto_tree_n = 0;
+        ctx->tm.algo = algo;
+    }
     if (algo == PCT_KNN_GRID_LEVELS) return run_levels();
     ctx->last_levels = false;
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
@@ -324,8 +335,9 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         PCT_TRY(bst);
         if (ctx->grid_skewed) {                    // the uniform list was not built: far too many cells per point
             ctx->grid_skewed = false;
-            ctx->auto_tree_n = ctx->n;
-            return run_tree();
+            const int st = run_tree();
+            if (st == PCT_OK && ctx->tm.algo == PCT_KNN_TREE) { ctx->auto_tree_n = ctx->n; memcpy(ctx->auto_tree_bbox, ctx->tree_bbox, sizeof(ctx->tree_bbox)); }
+            return st;
         }
         // PCT_KNN_AUTO on a whole cloud: is one cell size enough?  A point of a cloud of even density shares its cell
         // with about as many points as a non-empty cell holds on average; where the density spans decades the first
@@ -352,7 +364,11 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 // points the predicted share must be larger for the switch to pay)
                 const double fail_min = fmax(0.08, 37500.0 / (double)ctx->n);
                 if (ctx->auto_probe_tree ? fail > fail_min && cells < 15.0 : fail > 0.30 && fine > 0.02 * q && cells < 15.0) {
-                    if (ctx->auto_probe_tree) { ctx->auto_tree_n = ctx->n; return run_tree(); }
+                    if (ctx->auto_probe_tree) {
+                        const int st = run_tree();
+                        if (st == PCT_OK && ctx->tm.algo == PCT_KNN_TREE) { ctx->auto_tree_n = ctx->n; memcpy(ctx->auto_tree_bbox, ctx->tree_bbox, sizeof(ctx->tree_bbox)); }
+                        return st;
+                    }
                     return run_levels();
                 }
                 ctx->auto_tree_n = 0;

@@ -836,12 +836,13 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     // Warm start: a handle that sees a stream of similar clouds (same scanner, same shard of the same job) reuses
     // the edge the last build converged to, rescaled by the first-guess ratio, and so normally needs one pass.
     const double first_guess_raw = a;
+    bool hinted = false;                                  // the first edge comes from the previous cloud on this handle
     const bool level_pass = ctx->level_edge > 0;          // a later level of the density-adaptive sweep: edge given
     if (level_pass) {
         a = ctx->level_edge;
     } else if (ctx->hint_edge > 0 && ctx->hint_guess > 0) {
         const double r = first_guess_raw / ctx->hint_guess * sqrt(ctx->hint_target / target);   // guess ~ sqrt(target)
-        if (r > 0.5 && r < 2.0) a = ctx->hint_edge * r * sqrt(target / ctx->hint_target);
+        if (r > 0.5 && r < 2.0) { a = ctx->hint_edge * r * sqrt(target / ctx->hint_target); hinted = true; }
     }
     a = fmin(a, emax * 1.0001 + 1e-30);
 
@@ -883,10 +884,19 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         // PCT_KNN_AUTO: a surface wants about a third of a cell per point; an edge that asks for 16 cells per point was
         // steered there by a dense minority (the size-biased occupancy) -- a 1/r^2 scan wants 130 per point, 1.6 ms of
         // counters and scans that the hierarchical list does not need.  Nothing was built: the caller goes there.
-        if (ctx->auto_probe && !own_flag && g.ncell > 16 * n && g.ncell > ((int64_t)1 << 20)) {
-            ctx->grid_skewed = true;
-            ctx->grid_valid = false;
-            return PCT_OK;
+        if (!own_flag && !level_pass && g.ncell > 16 * n && g.ncell > ((int64_t)1 << 20)) {
+            if (it == 0 && hinted) {
+                // ... unless the edge is the PREVIOUS cloud's (same size, similar box, another density -- a torus after
+                // a 1/r^2 scan inherited its 130 cells per point): this cloud's own first guess, then
+                hinted = false;
+                a = fmin(first_guess_raw, emax * 1.0001 + 1e-30);
+                set_box();
+                set_dims(&g, bbox, a);
+            } else if (ctx->auto_probe) {
+                ctx->grid_skewed = true;
+                ctx->grid_valid = false;
+                return PCT_OK;
+            }
         }
         bool hit_cap = false;            // the cell budget, not the occupancy target, set this edge
         while (g.ncell > cell_cap) {

@@ -88,6 +88,8 @@ struct pct_ctx {
     // hierarchical cell list (pct_tree.hip)
     int tree_bits = 0;
     int64_t tree_segs = 0;
+    double tree_two_level_share = 1.0;   // share of the points on the two most populated adjacent octree levels (same sample)
+    int tree_level_spread = 0;      // octree levels between the 5th and 95th percentile of the points (a sample of the segments)
     pct_buf tree_codes, tree_vals;  // u64 / u32 (2 n): Morton codes and public positions, unsorted | sorted
     pct_buf tree_lvl;               // u8 (n): octree level every point is served at
     pct_buf tree_head, tree_marks;  // segment / item marks and their scans
@@ -104,6 +106,9 @@ struct pct_ctx {
     bool auto_probe = false;        // PCT_KNN_AUTO on a cloud the hierarchical list could take: pct_build_grid gives up (grid_skewed)
     bool auto_probe_tree = false;   // ... and the census that follows may send the call there
     bool grid_skewed = false;       // rather than build a uniform list of more than 16 cells per point
+    float auto_tree_bbox[6] = {0, 0, 0, 0, 0, 0};   // ... whose bounding box was this (the next cloud must match it within 2 %)
+    float tree_bbox[6] = {0, 0, 0, 0, 0, 0};        // bounding box of the cloud the hierarchical list was last built for
+    bool tree_check_bbox = false, tree_hint_mismatch = false;
     int64_t auto_tree_n = 0;        // PCT_KNN_AUTO sent a cloud of this size to the hierarchical list: the next one of the same
     int32_t auto_tree_calls = 0;    // size goes there directly (no uniform build first); re-examined every 16th call
     bool last_levels = false;       // the table in place came from pct_knn_levels            // a plain grid sweep of this cloud left > 5 % of the queries to the exact kernel
@@ -137,7 +142,7 @@ struct pct_ctx {
     pct_buf red;        // small reduction scratch
     // 4 KiB of pinned, device-visible host memory: kernels drop their few result words here so that a
     // read-back is one stream synchronisation, not a copy command.  [0,128) PackRed  [128,192) scan totals
-    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd  [2112,2144) work-item census of PCT_KNN_AUTO  [2176,2216) totals of the tree build
+    // [192,256) sweep counters  [256,1024) and [1024,1056) band statistics / band box of the density-adaptive sweep  [2048,2056) rows of the last fit that went to k_fit_svd  [2112,2144) work-item census of PCT_KNN_AUTO  [2176,2312) totals of the tree build
     unsigned char* pin = nullptr;
     int64_t n_occ = 0;
     bool grid_valid = false;

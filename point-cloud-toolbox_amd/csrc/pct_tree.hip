@@ -167,6 +167,7 @@ __global__ __launch_bounds__(256) void k_tree_items(const u64* __restrict__ code
         counts[0] = item + 1;
         counts[1] = seg + 1;
         counts[2] = counts[3] = 0;
+        for (int l = 0; l < 22; ++l) counts[4 + l] = 0;       // points per level, over a sample of the segments (k_tree_stencil)
         totals[0] = item + 1;
         totals[1] = seg + 1;
     }
@@ -205,6 +206,7 @@ __global__ __launch_bounds__(256) void k_tree_stencil(const u64* __restrict__ co
     int pop = r.y;
     for (int o = 16; o > 0; o >>= 1) pop += __shfl_xor(pop, o, 32);
     if (t == 0) {
+        if ((seg & 63) == 0) atomicAdd(&bad[2 + min(hd.x, 21)], seg_range[seg].y);   // one segment in 64: how many octaves of density the cloud spans
         seg_pop[seg] = pop;
         if (pop > cap && hd.x > 0) {
             atomicAdd(&bad[0], 1);                     // (device words: an atomic on pinned host memory is a PCIe round trip)
@@ -299,6 +301,15 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     *usable = false;
     PCT_TRY(pct_pack_points(ctx, bbox));                 // pts4 (public order) + bounding box; refuses non-finite input
     if (ctx->n_grid != n) return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep needs the whole cloud packed");
+    if (ctx->tree_check_bbox) {          // PCT_KNN_AUTO came here on a remembered verdict: is this still that kind of cloud?
+        bool same = true;
+        for (int a = 0; a < 3; ++a) {
+            const float tol = 0.02f * (ctx->auto_tree_bbox[3 + a] - ctx->auto_tree_bbox[a]) + 1e-30f;
+            same = same && fabsf(bbox[a] - ctx->auto_tree_bbox[a]) <= tol && fabsf(bbox[3 + a] - ctx->auto_tree_bbox[3 + a]) <= tol;
+        }
+        if (!same) { ctx->tree_hint_mismatch = true; return PCT_OK; }
+    }
+    for (int a = 0; a < 6; ++a) ctx->tree_bbox[a] = bbox[a];
     double ext = 0;
     for (int a = 0; a < 3; ++a) ext = fmax(ext, (double)bbox[3 + a] - bbox[a]);
     if (!(ext > 0)) ext = 1.0;
@@ -341,7 +352,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_TRY(pct_reserve(ctx, &ctx->row_of, (nn + 1) * sizeof(int)));
     if (ctx->has_f64) PCT_TRY(pct_reserve(ctx, &ctx->sorted4d, nn * sizeof(double4)));
     PCT_TRY(pct_reserve(ctx, &ctx->occ, (2 * nn + 16) * sizeof(int2)));          // items; refinement appends (<= one per point)
-    PCT_TRY(pct_reserve(ctx, &ctx->tree_range, (nn + 1) * (sizeof(int2) + sizeof(int)) + 64));
+    PCT_TRY(pct_reserve(ctx, &ctx->tree_range, (nn + 1) * (sizeof(int2) + sizeof(int)) + 128));
     u64* codes_in = (u64*)ctx->tree_codes.p;
     u64* codes = codes_in + nn;
     unsigned* vals_in = (unsigned*)ctx->tree_vals.p;
@@ -388,7 +399,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_TRY(pct_reserve(ctx, &ctx->tree_seg, (2 * nn + 2) * sizeof(int4)));
     int2* seg_range = (int2*)ctx->tree_range.p;
     int* seg_pop = (int*)(seg_range + nn + 1);
-    int* counts = seg_pop + nn + 1;                       // device: {items, segments, segments over the cap, their points}
+    int* counts = seg_pop + nn + 1;                       // device: {items, segments, segments over the cap, their points, points per level [22]}
     long long* totals = (long long*)(ctx->pin + 2176);    // host: {items, segments}
     hipLaunchKernelGGL(k_tree_items, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p,
                        (const int*)seg_start, (const u64*)sums, n, items_q, (int2*)ctx->occ.p, (int4*)ctx->tree_seg.p, seg_range, counts, totals);
@@ -412,9 +423,22 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     hipLaunchKernelGGL(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p,
                        (const int4*)ctx->tree_seg.p, (const int2*)seg_range, n_segs, cap, (int2*)ctx->tree_runs.p, seg_pop, counts + 2);
     PCT_HIP(ctx, hipGetLastError());
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 2208, counts, 4 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 2208, counts, 26 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     tick(3);
+    {   // levels between the 5th and the 95th percentile of the sampled points
+        const int* hist = (const int*)(ctx->pin + 2208) + 4;
+        long long tot = 0, acc = 0;
+        for (int l = 0; l < 22; ++l) tot += hist[l];
+        int lo = 0, hi = 21;
+        for (int l = 0; l < 22; ++l) { acc += hist[l]; if (acc * 20 >= tot) { lo = l; break; } }
+        acc = 0;
+        for (int l = 21; l >= 0; --l) { acc += hist[l]; if (acc * 20 >= tot) { hi = l; break; } }
+        ctx->tree_level_spread = tot > 0 && hi > lo ? hi - lo : 0;
+        long long best2 = 0;                   // share of the points on the two most populated ADJACENT levels
+        for (int l = 0; l + 1 < 22; ++l) best2 = best2 > (long long)hist[l] + hist[l + 1] ? best2 : (long long)hist[l] + hist[l + 1];
+        ctx->tree_two_level_share = tot > 0 ? (double)best2 / (double)tot : 1.0;
+    }
     const int64_t bad_segs = ((const int*)(ctx->pin + 2208))[2], bad_pts = ((const int*)(ctx->pin + 2208))[3];
     if (bad_segs > 0 && !getenv("PCT_TREE_NO_REFINE")) {
         if ((size_t)(n_segs + bad_pts) > room) {          // rare: most of the cloud is being split -- a larger table, contents kept
@@ -443,8 +467,8 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     }
     tick(4);
     if (debug)
-        fprintf(stderr, "[tree] %lld points: %lld items in %lld segments; %lld segments over %d stencil points (%lld points) split | codes+sort %.3f, "
-                "gather..items %.3f, stencil %.3f, refine %.3f ms\n", (long long)n, (long long)n_items, (long long)n_segs, (long long)bad_segs, cap,
+        fprintf(stderr, "[tree] %lld points: %lld items in %lld segments (levels spread %d, %.0f %% of the points on two adjacent levels); %lld segments over %d stencil points (%lld points) split | codes+sort %.3f, "
+                "gather..items %.3f, stencil %.3f, refine %.3f ms\n", (long long)n, (long long)n_items, (long long)n_segs, ctx->tree_level_spread, 100.0 * ctx->tree_two_level_share, (long long)bad_segs, cap,
                 (long long)bad_pts, t_mark[1] - t_mark[0], t_mark[2] - t_mark[1], t_mark[3] - t_mark[2], t_mark[4] - t_mark[3]);
 
     ctx->grid = g;

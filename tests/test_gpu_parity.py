@@ -1172,6 +1172,36 @@ def test_exact_sweeps_on_tiny_clouds_whose_last_batch_is_mostly_empty(gpu):
         h.close()
 
 
+def test_auto_remembers_an_uneven_cloud_and_forgets_when_a_different_one_follows(gpu):
+    """A handle fed a stream of clouds: after the census has sent one to the hierarchical cell list, the next one of the
+    same size AND the same bounding box (2 % per face: "the same scanner again") goes there directly, without a uniform
+    build first; any other cloud is examined afresh."""
+    capi = gpu["capi"]
+    rng = np.random.default_rng(19)
+    n = 300_000
+
+    def scan(seed):
+        g = np.random.default_rng(seed)
+        r, a = 0.01 * 100 ** g.uniform(0, 1, n), g.uniform(0, 2 * np.pi, n)
+        p = np.stack([r * np.cos(a), r * np.sin(a), np.zeros(n)], 1).astype(np.float32)
+        p[:4] = [(-1, -1, 0), (1, 1, 0), (-1, 1, 0), (1, -1, 0)]      # same extent whatever the draw
+        return p
+
+    torus = gpu["shapes"].torus_random(n, seed=6)
+    h = capi.Handle(0)
+    seen, grid_ms = [], []
+    for pts in (scan(1), scan(2), torus, torus, scan(3), scan(4)):
+        h.set_points(pts)
+        h.curvature(30, 0.0, capi.KNN_AUTO)
+        t = h.timings()
+        seen.append(t["algo"])
+        grid_ms.append(t["grid_ms"])
+    h.close()
+    T, G = capi.KNN_TREE, capi.KNN_GRID
+    assert seen == [T, T, G, G, T, T], seen
+    del rng
+
+
 def test_chain_window_and_histogram_agree_at_a_bin_boundary(gpu):
     """Found by tools/fuzz_gpu.py (seed 31, case 5827): a float64 cloud far from the origin, quantised by float32 into
     piles of identical points -- every pending query of the chained sweep wanted exactly the edge of a histogram bin
