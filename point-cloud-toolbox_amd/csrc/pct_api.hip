@@ -264,6 +264,7 @@ int pct_set_stats(pct_ctx* ctx, int32_t enable) {
 // neighbour sweep without timing bookkeeping; events 2..4 bracket grid / sweep
 static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_fit = false) {
     ctx->levels_fitted = false;
+    ctx->skip_dist_req = fuse_fit;
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
     if (k < 1 || k > 127) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,127]", k);
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);

@@ -157,6 +157,8 @@ struct pct_ctx {
     double eps = 0.0;
     bool knn_valid = false;
     bool knn_sorted_space = false; // false: rows/ids are public indices (brute force)
+    bool skip_dist_req = false;    // the caller will not read distances from the table (the fused curvature call)
+    bool dist_valid = true;        // nbr_dist holds the distances of the table in place (else: derived on demand)
     pct_buf counters;   // int64[4] device counters (fallbacks, overflows)
 
     // results, public order

@@ -297,7 +297,7 @@ struct Sweep {
             const bool real = best.p[r] != INT_MAX;
             if (i >= 1 && i <= k) {
                 nbr_pos[row * pitch + (i - 1)] = real ? best.p[r] : -1;
-                nbr_dist[row * pitch + (i - 1)] = real ? (float)sqrt(best.d[r]) : INFINITY;
+                if (nbr_dist) nbr_dist[row * pitch + (i - 1)] = real ? (float)sqrt(best.d[r]) : INFINITY;
                 found += real;
             }
         }
@@ -1720,6 +1720,464 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? (R == 1 ? (PCT_TREE_CAP
 }
 
 // ---------------------------------------------------------------------------
+// k_knn_pair: the fast sweep for the case the headline workload is -- one list register (k + 1 <= 64), a float32 cloud,
+// the uniform cell list, a plain sweep (no level pass) -- written for the SCALAR unit as much as for the vector units.
+// Same algorithm, same proofs and bit-identical rows as k_knn_fast<1, EPS, true, true>; what differs:
+//   * the kernel argument holds only what this kernel reads, the work item's cell coordinates come from two
+//     multiplications (host-side magic numbers) instead of three integer divisions, per-item bases replace the
+//     per-query 64-bit row arithmetic, and the opt-in statistics do not live in the loop: no scalar register spills
+//     (k_knn_fast: 31 at the 106-register cap);
+//   * the threshold search of the two queries of a pair runs in lanes 0 and 1 of the same vector instructions
+//     (one secant step serves both) and leaves the loop with one ballot;
+//   * the compaction of the survivors has no divergent region: a lane without a survivor writes to a spare slot
+//     (k_knn_fast: s_and_saveexec / s_or exec and a branch per batch and query);
+//   * exact keys, distances and positions of both queries are worked out for all 64 lanes in one basic block (the two
+//     fp64 chains interleave; lanes beyond the survivor count are set to padding afterwards);
+//   * the two sorting networks are ONE hand-scheduled assembly block (pct_sort_pair.inc, tools/gen_sort_asm.py): the
+//     sets alternate instruction by instruction, so the wait states of every DPP read are the other set's work
+//     (10 s_nop per pair instead of 40, 82 VALU instead of 99, both ds_bpermute of a flip in flight together);
+//   * DIST = false (the fused curvature call, whose fit never reads distances) leaves out the correctly rounded
+//     float32(sqrt(fp64)) and the second table: pct_get_neighbors derives the same bits from the positions on demand.
+// Staged batches are used in pairs (128 slots); the body is compiled per number of pairs in use, without guards
+// (1 | 2 | 3 | 4): slots of a staged pair beyond the stencil's population sit at +inf.
+// ---------------------------------------------------------------------------
+#include "pct_sort_pair.inc"
+
+__device__ __forceinline__ void sort_pair_asm(unsigned& ea, unsigned& eb, const SortLanes& c) {
+    unsigned ta, tb;
+    asm volatile(PCT_SORT_PAIR_ASM
+                 : [ea] "+v"(ea), [eb] "+v"(eb), [ta] "=&v"(ta), [tb] "=&v"(tb)
+                 : [sel0] "v"(c.sel[0]), [sel1] "v"(c.sel[1]), [sel2] "v"(c.sel[2]), [sel3] "v"(c.sel[3]), [sel4] "v"(c.sel[4]),
+                   [sel5] "v"(c.sel[5]), [a31] "v"(c.a31), [a63] "v"(c.a63));
+    ea = PCT_SORT_PAIR_RESULT_A;
+    eb = PCT_SORT_PAIR_RESULT_B;
+}
+
+struct PairArgs {
+    const float4* pts;        // cell-sorted candidate records {x, y, z, public index}
+    const int* cell_start;
+    const int* cell_own;
+    const int* own_start;
+    const int2* items;        // work items {cell, chunk of items_q queries}
+    int* nbr_pos;
+    float* nbr_dist;          // unused when DIST = false
+    int* nbr_cnt;             // EPS only
+    int* redo;
+    int* redo_count;
+    unsigned long long* counters;
+    int n_items, items_q;
+    int k, pitch;
+    int stats;
+    unsigned magic_x, magic_xy;      // cell -> (cx, cy, cz) by multiplication: q = (x * magic) >> shift, exact for x < 2^30
+    int shift_x, shift_xy;
+    double eps2;
+    pct_grid g;
+};
+
+constexpr int kPairCap = kStageCap;
+static_assert((kPairCap & (kPairCap - 1)) == 0 && kPairCap % 128 == 0 && kPairCap <= 512, "staging capacity of k_knn_pair");
+struct PairLds {
+    float cx[kPairCap], cy[kPairCap], cz[kPairCap];      // staged stencil, 12 B per candidate
+    unsigned pend[64 + 4];                               // staged slots of the survivors of query a; [64]: the spare slot
+    unsigned short pend_b[64 + 8];                       // ... of query b
+    int offc[16];                                        // sorted position - flat slot, per non-empty run
+};
+
+template <bool EPS, bool DIST>
+__global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
+    constexpr int CAP = kPairCap, LIST = 64, SLOT_BITS = 6, KEY_BITS = 32 - SLOT_BITS;
+    __shared__ PairLds s_lds[4];
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = lane_id();
+    const int item = (int)blockIdx.x * 4 + w;
+    if (item >= a.n_items) return;
+    PairLds& L = s_lds[w];
+    const SortLanes sort_dir = make_sort_lanes();
+    const int* __restrict__ cs = a.cell_start;
+
+    const int2 it2 = a.items[item];
+    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+    const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+    const int cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
+    const int rem = cell - cz * (nx * ny);
+    const int cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
+    const int cx = rem - cy * nx;
+    const int c0 = cs[cell];
+    const int qs = c0 + chunk * a.items_q;                        // owned points sit first in the cell
+    const int nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
+    const int row0 = a.own_start[cell] + chunk * a.items_q;       // neighbour-table row of query qs
+
+    // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+    int run_s = 0, run_len = 0;
+    if (lane < 9) {
+        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+        if (z >= 0 && z < nz && y >= 0 && y < ny) {
+            const int row = (z * ny + y) * nx;
+            run_s = cs[row + max(cx - 1, 0)];
+            run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+        }
+    }
+    // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
+    float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < nq) my_q = a.pts[qs + lane];
+    // exclusive prefix of the run lengths over lanes 0..8 = first flat slot of every run; m = staged candidates
+    int my_pre = 0, m = 0;
+    {
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            my_pre = lane == t ? acc : my_pre;
+            acc += __builtin_amdgcn_readlane(run_len, t);
+        }
+        m = acc;
+    }
+    if (m > CAP) {
+        // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.redo_count, nq);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < nq) a.redo[base + lane] = row0 + lane;
+        if (a.stats && lane == 0) {
+            atomicAdd(&a.counters[1], 1ull);
+            atomicAdd(&a.counters[4], (unsigned long long)nq);
+        }
+        return;
+    }
+
+    // ---- copy the runs as one flat range (see k_knn_fast): run starts as a bit string in the list area, run index of
+    // this lane's slots in 4 bits per batch (run_code), offc[u] = sorted position - flat slot of run u
+    unsigned run_code = 0u;
+    static_assert(CAP / 64 <= 8, "run_code holds eight batches");
+    {
+        unsigned* bits = L.pend;
+        if (lane < CAP / 32) bits[lane] = 0u;
+        wave_lds_sync();
+        const bool nonempty = lane < 9 && run_len > 0;
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
+        if (nonempty) {
+            atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
+            L.offc[__builtin_amdgcn_mbcnt_lo((unsigned)ne, 0)] = run_s - my_pre;
+        }
+        wave_lds_sync();
+        float4 tmp[CAP / 64];
+        int ubase = -1;
+#pragma unroll
+        for (int b = 0; b < CAP / 64; ++b) {
+            tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (b * 64 < m) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b]);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b + 1]);
+                const unsigned long long B = ((unsigned long long)hi << 32) | lo;
+                const unsigned long long S = B >> 1;               // starts <= lane  =  starts of (B >> 1) below lane, + bit 0
+                const int s0 = ubase + (int)(lo & 1u);
+                const int u = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(S >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)S, (unsigned)s0));
+                ubase += (int)__popcll(B);
+                const int j = b * 64 + lane;
+                run_code |= (unsigned)u << (4 * b);
+                if (j < m) tmp[b] = a.pts[j + L.offc[u]];
+            }
+        }
+        wave_lds_sync();                      // the bit string is dead: the list area goes back to the queries
+#pragma unroll
+        for (int b = 0; b < CAP / 64; ++b) {
+            const int j = b * 64 + lane;
+            if (j < m) {
+                L.cx[j] = tmp[b].x; L.cy[j] = tmp[b].y; L.cz[j] = tmp[b].z;
+            } else if ((b & ~1) * 64 < m) {
+                L.cx[j] = INFINITY; L.cy[j] = 0.f; L.cz[j] = 0.f;     // unused slot of a staged pair: passes no threshold
+            }
+        }
+    }
+    wave_lds_sync();
+
+    const int k = a.k;
+    const double eps2 = EPS ? a.eps2 : (double)INFINITY;
+    constexpr double kKeyRange = 2.3;                     // what the 27-cell cube can vouch for, in cell^2 (k_knn_fast)
+    const double edge = a.g.cell;
+    const double scale = (double)(1u << KEY_BITS) / (kKeyRange * edge * edge);
+    constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
+    unsigned my_gkey;                                     // per query (lane l = query l): the largest key the stencil vouches for
+    {
+        const double gx = ((double)my_q.x - a.g.ox) * a.g.inv_cell - cx;
+        const double gy = ((double)my_q.y - a.g.oy) * a.g.inv_cell - cy;
+        const double gz = ((double)my_q.z - a.g.oz) * a.g.inv_cell - cz;
+        const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
+        my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
+    }
+    const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
+    const float cell2f = (float)(edge * edge);
+    const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
+    float t_prev_f = 0.f;                                 // threshold of the previous query of this item (0 = none yet)
+    unsigned long long redo_mask = 0ull;                  // queries of this item the exact sweep has to take
+
+    // table rows of this item: one 64-bit base per item, 32-bit offsets per query and lane (list entry i -> column i - 1)
+    char* const pos_item = (char*)(a.nbr_pos + (int64_t)row0 * a.pitch);
+    char* const dist_item = DIST ? (char*)(a.nbr_dist + (int64_t)row0 * a.pitch) : nullptr;
+    const unsigned lane_off = (unsigned)(lane - 1) * 4u;
+    const unsigned pitch4 = (unsigned)a.pitch * 4u;
+    const bool col_lane = lane >= 1 && lane <= k;         // lanes whose list entry is a table column
+
+    const auto slot_to_pos = [&](int j) {
+        const unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code);
+        return j + L.offc[(code >> (((unsigned)j >> 6) << 2)) & 15u];
+    };
+
+    const auto pair_loop = [&](auto NBP_) {
+        constexpr int NBP = decltype(NBP_)::value, NBU = 2 * NBP;
+        for (int qi = 0; qi < nq; qi += 2) {
+            const bool live_b = qi + 1 < nq;             // an odd tail runs its last query twice, the copy is discarded
+            const int qj = live_b ? qi + 1 : qi;
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+            const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
+            const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
+            const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
+            // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
+            float ap_a[NBU], ap_b[NBU];
+#pragma unroll
+            for (int p2 = 0; p2 < NBP; ++p2) {
+                const int sa = p2 * 128 + lane, sb = sa + 64;
+                const float2v vx = {L.cx[sa], L.cx[sb]}, vy = {L.cy[sa], L.cy[sb]}, vz = {L.cz[sa], L.cz[sb]};
+                {
+                    const float2v dx = vx - ax, dy = vy - ay, dz = vz - az;
+                    float2v d = dx * dx;
+                    d = __builtin_elementwise_fma(dy, dy, d);
+                    d = __builtin_elementwise_fma(dz, dz, d);
+                    ap_a[2 * p2] = d.x;
+                    ap_a[2 * p2 + 1] = d.y;
+                }
+                {
+                    const float2v dx = vx - bx, dy = vy - by, dz = vz - bz;
+                    float2v d = dx * dx;
+                    d = __builtin_elementwise_fma(dy, dy, d);
+                    d = __builtin_elementwise_fma(dz, dz, d);
+                    ap_b[2 * p2] = d.x;
+                    ap_b[2 * p2 + 1] = d.y;
+                }
+            }
+            // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball.  Lane 0 searches for
+            // query a, lane 1 for query b: the counts are wave-wide ballots, the secant arithmetic is per lane.
+            const float T_init = eps2a;                       // +inf without eps
+            int tot_a = m, tot_b = m;
+            if constexpr (EPS) {
+                tot_a = tot_b = 0;
+#pragma unroll
+                for (int b = 0; b < NBU; ++b) {
+                    tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < T_init));
+                    tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < T_init));
+                }
+            }
+            const bool need_a = tot_a > LIST, need_b = live_b && tot_b > LIST;
+            float T_a = T_init, T_b = T_init;
+            int cnt_a = tot_a, cnt_b = tot_b;
+            bool ok_a = true, ok_b = live_b;
+            unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;     // exact keys of the candidates the pre-selection cut are >= bkey
+            if (need_a || need_b) {
+                const float target = 0.5f * (float)(k + 1 + LIST);
+                float t0 = t_prev_f > 0.f ? t_prev_f : cell2f;
+                if (!(t0 < T_init)) t0 = 0.5f * T_init;
+                const bool mine = lane == 0 ? need_a : need_b;         // (lanes >= 2 mirror lane 1; nobody reads them)
+                float v_t = t0, v_lo = 0.f, v_hi = T_init, v_T = T_init;
+                int v_cnt = lane == 0 ? tot_a : tot_b;
+                bool go = mine, found = !mine;
+#pragma unroll 1
+                for (int trial = 0; trial < 16; ++trial) {
+                    const float ta = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_t), 0));
+                    const float tb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_t), 1));
+                    int c_a = 0, c_b = 0;
+#pragma unroll
+                    for (int b = 0; b < NBU; ++b) {
+                        c_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < ta));
+                        c_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < tb));
+                    }
+                    const int c = lane == 0 ? c_a : c_b;
+                    const bool in = go && c >= k + 1 && c <= LIST;
+                    v_T = in ? v_t : v_T;
+                    v_cnt = in ? c : v_cnt;
+                    found = found || in;
+                    go = go && !in;
+                    const bool below = c < k + 1;
+                    v_lo = go && below ? v_t : v_lo;
+                    v_hi = go && !below ? v_t : v_hi;
+                    float nt = c > 0 ? v_t * target * __builtin_amdgcn_rcpf((float)c) : 4.f * v_t;
+                    if (!(nt > v_lo && nt < v_hi)) nt = v_hi < INFINITY ? 0.5f * (v_lo + v_hi) : 2.f * v_lo;
+                    go = go && nt > v_lo && nt < v_hi;         // no float left between: a pile of equal distances
+                    v_t = go ? nt : v_t;
+                    if ((__builtin_amdgcn_ballot_w64(go) & 3ull) == 0ull) break;
+                }
+                const unsigned fm = (unsigned)__builtin_amdgcn_ballot_w64(found);
+                T_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_T), 0));
+                T_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v_T), 1));
+                cnt_a = __builtin_amdgcn_readlane(v_cnt, 0);
+                cnt_b = __builtin_amdgcn_readlane(v_cnt, 1);
+                // smallest exact key a candidate cut by the float32 threshold T can have: its float32 d^2 >= T means the
+                // exact d^2 >= T (1 - 2^-20) (arithmetic error of the packed evaluation)
+                const unsigned v_bkey = (unsigned)fmin((double)v_T * (1.0 - 0x1p-20) * scale, 4294967294.0);
+                ok_a = (fm & 1u) != 0u && (!need_a || T_a >= 1e-30f);
+                ok_b = live_b && (fm & 2u) != 0u && (!need_b || T_b >= 1e-30f);
+                if (need_a && ok_a) { t_prev_f = T_a; bkey_a = (unsigned)__builtin_amdgcn_readlane((int)v_bkey, 0); }
+                if (need_b && ok_b) { t_prev_f = T_b; bkey_b = (unsigned)__builtin_amdgcn_readlane((int)v_bkey, 1); }
+                if (!ok_a) { redo_mask |= 1ull << qi; T_a = 0.f; cnt_a = 0; }        // nothing passes, nothing is stored
+                if (!ok_b) { if (live_b) redo_mask |= 1ull << qj; T_b = 0.f; cnt_b = 0; }
+                if (!ok_a && !ok_b) continue;
+            }
+            if (!live_b) { T_b = 0.f; cnt_b = 0; }
+            // ---- compact the slots of the survivors of both queries.  Per batch and query: one compare (the pass mask
+            // goes to a scalar pair), two v_mbcnt for the rank among the survivors, one v_lshl_add for the LDS address --
+            // four vector instructions -- and the write under exec = mask; the running list address and exec are
+            // scalar work (the scalar unit has the room: the kernel is bound by vector issue, 4 cycles per instruction).
+            // Hand-placed: on gfx940-class parts a VALU read of an SGPR needs two wait states after the VALU write of
+            // it; the two queries' instructions fill each other's.
+            {
+                unsigned wr_a = (unsigned)(uintptr_t)&L.pend[0], wr_b = (unsigned)(uintptr_t)&L.pend_b[0];
+                const unsigned long long all = __builtin_amdgcn_read_exec();
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NBU; ++b) {
+                    unsigned ra, rb, ca, cb;
+                    const unsigned slot = (unsigned)(b * 64 + lane);
+                    asm volatile(
+                        "v_cmp_gt_f32 vcc, %[ta], %[apa]\n"
+                        "v_cmp_gt_f32 s[96:97], %[tb], %[apb]\n"
+                        "s_bcnt1_i32_b64 %[ca], vcc\n"
+                        "v_mbcnt_lo_u32_b32 %[ra], vcc_lo, 0\n"
+                        "s_bcnt1_i32_b64 %[cb], s[96:97]\n"
+                        "v_mbcnt_lo_u32_b32 %[rb], s96, 0\n"
+                        "v_mbcnt_hi_u32_b32 %[ra], vcc_hi, %[ra]\n"
+                        "v_mbcnt_hi_u32_b32 %[rb], s97, %[rb]\n"
+                        "v_lshl_add_u32 %[ra], %[ra], 2, %[wra]\n"
+                        "v_lshl_add_u32 %[rb], %[rb], 1, %[wrb]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_write_b32 %[ra], %[slot]\n"
+                        "s_mov_b64 exec, s[96:97]\n"
+                        "ds_write_b16 %[rb], %[slot]\n"
+                        "s_mov_b64 exec, %[all]\n"
+                        "s_lshl2_add_u32 %[wra], %[ca], %[wra]\n"
+                        "s_lshl1_add_u32 %[wrb], %[cb], %[wrb]\n"
+                        : [ra] "=&v"(ra), [rb] "=&v"(rb), [ca] "=&s"(ca), [cb] "=&s"(cb), [wra] "+s"(wr_a), [wrb] "+s"(wr_b)
+                        : [ta] "v"(T_a), [tb] "v"(T_b), [apa] "v"(ap_a[b]), [apb] "v"(ap_b[b]), [slot] "v"(slot), [all] "s"(all)
+                        : "vcc", "scc", "s96", "s97", "memory");
+                }
+                wave_lds_sync();
+            }
+            // ---- exact keys for the survivors only.  Survivor `lane` of each query: staged slot -> coordinates -> fp64
+            // ((dx^2 + dy^2) + dz^2) (no FMA: SciPy's value) -> key, distance, sorted position; worked out by every lane
+            // (a stale list entry is masked into the staging area and gives a garbage value nobody uses).
+            const int ja = (int)L.pend[lane] & (CAP - 1), jb = (int)L.pend_b[lane] & (CAP - 1);
+            const int out_pa = slot_to_pos(ja), out_pb = slot_to_pos(jb);
+            float out_da = 0.f, out_db = 0.f;
+            unsigned e_a, e_b;
+            {
+                const double dxa = (double)L.cx[ja] - (double)ax, dya = (double)L.cy[ja] - (double)ay, dza = (double)L.cz[ja] - (double)az;
+                const double dxb = (double)L.cx[jb] - (double)bx, dyb = (double)L.cy[jb] - (double)by, dzb = (double)L.cz[jb] - (double)bz;
+                const double d2a = (dxa * dxa + dya * dya) + dza * dza;
+                const double d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
+                if constexpr (DIST) {
+                    out_da = (float)sqrt(d2a);
+                    out_db = (float)sqrt(d2b);
+                }
+                const unsigned ka = (min((unsigned)(d2a * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+                const unsigned kb = (min((unsigned)(d2b * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+                e_a = lane < cnt_a && (!EPS || d2a < eps2) ? ka : kPadElem;
+                e_b = lane < cnt_b && (!EPS || d2b < eps2) ? kb : kPadElem;
+            }
+            wave_lds_sync();
+            sort_pair_asm(e_a, e_b, sort_dir);
+            // ---- proof obligations per query (all in key units, see k_knn_fast) ------------------------------------
+            const unsigned tau_a = (unsigned)__builtin_amdgcn_readlane((int)e_a, k);      // the (k+1)-th nearest (padding if fewer exist)
+            const unsigned tau_b = (unsigned)__builtin_amdgcn_readlane((int)e_b, k);
+            const unsigned g_a = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
+            const unsigned g_b = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qj);
+            const unsigned tk_a = tau_a >> SLOT_BITS, tk_b = tau_b >> SLOT_BITS;
+            const unsigned need_ka = min(tau_a == kPadElem ? 0xFFFFFFFFu : tk_a + 1u, eps_key);
+            const unsigned need_kb = min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key);
+            const bool amb_a = need_ka > min(g_a, bkey_a) || (tau_a != kPadElem && tk_a >= key_max - 1u);
+            const bool amb_b = need_kb > min(g_b, bkey_b) || (tau_b != kPadElem && tk_b >= key_max - 1u);
+            if (ok_a && amb_a) { redo_mask |= 1ull << qi; ok_a = false; }
+            if (ok_b && amb_b) { redo_mask |= 1ull << qj; ok_b = false; }
+            // equal keys among the first k+2 entries: ordered here by the exact values (order_equal_keys)
+            {
+                const unsigned up_a = (unsigned)__builtin_amdgcn_update_dpp((int)kPadElem, (int)e_a, 0x130, 0xF, 0xF, false);   // wave_shl:1 = element i + 1
+                const unsigned up_b = (unsigned)__builtin_amdgcn_update_dpp((int)kPadElem, (int)e_b, 0x130, 0xF, 0xF, false);
+                const bool col_a = lane <= k && up_a != kPadElem && ((e_a ^ up_a) >> SLOT_BITS) == 0u;     // (a real element sorts below padding)
+                const bool col_b = lane <= k && up_b != kPadElem && ((e_b ^ up_b) >> SLOT_BITS) == 0u;
+                const unsigned long long cm_a = __builtin_amdgcn_ballot_w64(col_a), cm_b = __builtin_amdgcn_ballot_w64(col_b);
+                if (__builtin_expect((cm_a | cm_b) != 0ull, 0)) {
+                    if (ok_a && cm_a != 0ull) {
+                        const double ux = (double)ax, uy = (double)ay, uz = (double)az;
+                        const bool done = order_equal_keys<1, SLOT_BITS>(&e_a, a.pts,
+                            [&](unsigned at) {
+                                const int j = (int)L.pend[at] & (CAP - 1);
+                                const double dx = (double)L.cx[j] - ux, dy = (double)L.cy[j] - uy, dz = (double)L.cz[j] - uz;
+                                return (dx * dx + dy * dy) + dz * dz;
+                            },
+                            [&](unsigned at) { return __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_pa); });
+                        if (!done) { redo_mask |= 1ull << qi; ok_a = false; }
+                    }
+                    if (ok_b && cm_b != 0ull) {
+                        const double ux = (double)bx, uy = (double)by, uz = (double)bz;
+                        const bool done = order_equal_keys<1, SLOT_BITS>(&e_b, a.pts,
+                            [&](unsigned at) {
+                                const int j = (int)L.pend_b[at] & (CAP - 1);
+                                const double dx = (double)L.cx[j] - ux, dy = (double)L.cy[j] - uy, dz = (double)L.cz[j] - uz;
+                                return (dx * dx + dy * dy) + dz * dz;
+                            },
+                            [&](unsigned at) { return __builtin_amdgcn_ds_bpermute((int)(at & 63u) << 2, out_pb); });
+                        if (!done) { redo_mask |= 1ull << qj; ok_b = false; }
+                    }
+                }
+            }
+            // ---- store: the lane that holds list entry i fetches position (and distance) of survivor e & 63 ----------
+            {
+                const unsigned off_a = lane_off + (unsigned)qi * pitch4, off_b = lane_off + (unsigned)qj * pitch4;
+                const bool real_a = e_a != kPadElem, real_b = e_b != kPadElem;
+                const int at_a = (int)(e_a & 63u) << 2, at_b = (int)(e_b & 63u) << 2;
+                const int pos_a = __builtin_amdgcn_ds_bpermute(at_a, out_pa), pos_b = __builtin_amdgcn_ds_bpermute(at_b, out_pb);
+                float dist_a = 0.f, dist_b = 0.f;
+                if constexpr (DIST) {
+                    dist_a = __int_as_float(__builtin_amdgcn_ds_bpermute(at_a, __float_as_int(out_da)));
+                    dist_b = __int_as_float(__builtin_amdgcn_ds_bpermute(at_b, __float_as_int(out_db)));
+                }
+                if (ok_a && col_lane) {
+                    *(int*)(pos_item + off_a) = real_a ? pos_a : -1;
+                    if constexpr (DIST) *(float*)(dist_item + off_a) = real_a ? dist_a : INFINITY;
+                }
+                if (ok_b && col_lane) {
+                    *(int*)(pos_item + off_b) = real_b ? pos_b : -1;
+                    if constexpr (DIST) *(float*)(dist_item + off_b) = real_b ? dist_b : INFINITY;
+                }
+                if constexpr (EPS) {
+                    const int f_a = (int)__popcll(__builtin_amdgcn_ballot_w64(real_a && col_lane));
+                    const int f_b = (int)__popcll(__builtin_amdgcn_ballot_w64(real_b && col_lane));
+                    if (lane == 0) {
+                        if (ok_a) a.nbr_cnt[row0 + qi] = f_a;
+                        if (ok_b) a.nbr_cnt[row0 + qj] = f_b;
+                    }
+                }
+            }
+        }
+    };
+    {
+        using std::integral_constant;
+        const int nbp = (m + 127) >> 7;
+        if (nbp <= 1) pair_loop(integral_constant<int, 1>{});
+        else if (nbp == 2) pair_loop(integral_constant<int, 2>{});
+        else if (nbp == 3) pair_loop(integral_constant<int, (CAP >= 384 ? 3 : 1)>{});
+        else pair_loop(integral_constant<int, (CAP >= 512 ? 4 : 1)>{});
+    }
+    if (redo_mask) {
+        const int cnt = (int)__popcll(redo_mask);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.redo_count, cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((redo_mask >> lane) & 1ull) a.redo[base + (int)__popcll(redo_mask & ((1ull << lane) - 1ull))] = row0 + lane;
+        if (a.stats && lane == 0) atomicAdd(&a.counters[4], (unsigned long long)cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Exhaustive sweep: wave = query, candidates streamed from global in public
 // order (coalesced 1 KiB per wave instruction).  Exact at any N; used for small
 // clouds and as the on-device cross-check of the grid sweep.
@@ -1813,6 +2271,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_query_points(const floa
     }
 }
 
+// The float32 distance of a table entry, from the two records: the sweep's own expression -- fp64 ((dx^2 + dy^2) +
+// dz^2) without contraction, correctly rounded root, one rounding to float32 (pct:78) -- so a table written without
+// distances (the fused curvature call) yields the very bits the sweep would have stored.
+__device__ __forceinline__ float table_distance(const float4 q, const float4 c) {
+    const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
+    return (float)sqrt((dx * dx + dy * dy) + dz * dz);
+}
+
 // neighbour table -> public (rows,k) arrays for public rows [begin,end).  owned_pos == nullptr: the table came
 // from the exhaustive sweep (row = public index - q_begin, entries = public indices).
 __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ owned_pos, int q_begin,
@@ -1828,13 +2294,14 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
     if (pub < begin || pub >= end) return;
     const int64_t o = (int64_t)(pub - begin) * k + j;
     const int pos = nbr_pos[row * pitch + j];
-    if (idx_out) idx_out[o] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
-    if (dist_out) dist_out[o] = nbr_dist[row * pitch + j];
+    const float4 c = pos < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pts[pos];
+    if (idx_out) idx_out[o] = pos < 0 ? (int)n : __float_as_int(c.w);
+    if (dist_out) dist_out[o] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts[owned_pos[row]], c);
     if (cnt_out && j == 0) cnt_out[pub - begin] = nbr_cnt ? nbr_cnt[row] : k;
 }
 
 // the same for an explicit list of public rows (one block per listed row)
-__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ row_of, int q_begin,
+__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ row_of, const int* __restrict__ owned_pos, int q_begin,
                                                      const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
                                                      const int* __restrict__ nbr_cnt, int64_t n, int k, int pitch,
                                                      const int64_t* __restrict__ rows, int* __restrict__ idx_out,
@@ -1844,8 +2311,9 @@ __global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ 
     const int64_t row = row_of ? row_of[pub - q_begin] : pub - q_begin;
     for (int j = threadIdx.x; j < k; j += 128) {
         const int pos = nbr_pos[row * pitch + j];
-        if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(pts[pos].w);
-        if (dist_out) dist_out[r * k + j] = nbr_dist[row * pitch + j];
+        const float4 c = pos < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pts[pos];
+        if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(c.w);
+        if (dist_out) dist_out[r * k + j] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts[owned_pos[row]], c);
     }
     if (cnt_out && threadIdx.x == 0) cnt_out[r] = nbr_cnt ? nbr_cnt[row] : k;
 }
@@ -1932,11 +2400,12 @@ KnnArgs make_args(pct_ctx* ctx, int32_t k, double eps, bool grid) {
     return a;
 }
 
-int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
+int reserve_table(pct_ctx* ctx, int32_t k, double eps, bool with_dist = true) {
     ctx->nbr_pitch = (k + 3) & ~3;                        // 16-byte aligned rows (the fit kernel reads int4)
     const size_t rows = (size_t)(ctx->own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin);     // one row per owned query
     PCT_TRY(pct_reserve(ctx, &ctx->nbr_pos, rows * ctx->nbr_pitch * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, rows * ctx->nbr_pitch * sizeof(float)));
+    if (with_dist) PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, rows * ctx->nbr_pitch * sizeof(float)));
+    ctx->dist_valid = with_dist;
     if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, rows * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
     PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
@@ -1949,12 +2418,22 @@ int reserve_table(pct_ctx* ctx, int32_t k, double eps) {
 // phase 1: fast sweep only, the flagged rows stay in ctx->redo (level passes); phase 2: exact sweep of ctx->redo
 int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, int phase) {
     const int64_t n_rows = ctx->own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
+    // The plain sweep of a float32 cloud with one list register goes to the scalar-lean kernel (k_knn_pair); there the
+    // fused curvature call, whose fit never reads distances, writes no distance table (pct_get_neighbors derives the
+    // same bits from the positions when asked).
+    const double c2_ = ctx->grid.cell * ctx->grid.cell;                // (the float32 pre-selection's range, see f32_ok below)
+    const bool f32_ok_ = c2_ > 1e-30 && c2_ < 1e30 && (!(eps > 0) || eps * eps > 1e-36);
+    const bool pair_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
+                             k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !getenv("PCT_NO_PAIR") &&
+                             !getenv("PCT_NO_PAIR_KERNEL");
+    const bool skip_dist = pair_kernel && ctx->skip_dist_req && !getenv("PCT_KEEP_DIST");
     if (phase != 2) {
-        PCT_TRY(reserve_table(ctx, k, eps));
+        PCT_TRY(reserve_table(ctx, k, eps, !skip_dist));
         PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
         if (ctx->level_mode) PCT_TRY(pct_reserve(ctx, &ctx->redo_m, ((size_t)n_rows + 16) * sizeof(int)));
     }
     KnnArgs a = make_args(ctx, k, eps, true);
+    if (!ctx->dist_valid) a.nbr_dist = nullptr;
     int* redo_count = (int*)ctx->counters.p + 14;            // counters buffer: 8 x u64, last int pair reserved
     int* redo = (int*)ctx->redo.p;
     const dim3 block(64 * kWavesPerBlock);
@@ -1982,6 +2461,29 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
     hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
     hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        // the plain sweep of a float32 cloud with one list register: the scalar-lean kernel (k_knn_pair)
+        if (pair_kernel && pre) {
+            PairArgs pa = {};
+            pa.pts = a.pts; pa.cell_start = a.cell_start; pa.cell_own = a.cell_own; pa.own_start = a.own_start;
+            pa.items = items;
+            pa.nbr_pos = a.nbr_pos; pa.nbr_dist = a.nbr_dist; pa.nbr_cnt = a.nbr_cnt;
+            pa.redo = redo; pa.redo_count = redo_count; pa.counters = a.counters;
+            pa.n_items = (int)ctx->n_items; pa.items_q = ctx->items_q;
+            pa.k = a.k; pa.pitch = a.pitch; pa.stats = a.stats; pa.eps2 = a.eps2; pa.g = a.g;
+            // x / d = (x * magic) >> shift for every x < 2^30 (cell ids): shift = 30 + ceil(log2 d), magic = ceil(2^shift / d) < 2^32
+            const auto magic = [](unsigned d, unsigned* mg, int* sh) {
+                int l = 0;
+                while ((1ull << l) < d) ++l;
+                *sh = 30 + l;
+                *mg = (unsigned)(((1ull << *sh) + d - 1) / d);
+            };
+            magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
+            magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
+            if (e && skip_dist) hipLaunchKernelGGL((k_knn_pair<true, false>), grid1, block1, 0, ctx->stream, pa);
+            else if (e) hipLaunchKernelGGL((k_knn_pair<true, true>), grid1, block1, 0, ctx->stream, pa);
+            else if (skip_dist) hipLaunchKernelGGL((k_knn_pair<false, false>), grid1, block1, 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((k_knn_pair<false, true>), grid1, block1, 0, ctx->stream, pa);
+        } else
         if (q64_ok && !no_pair) {
             if (r1 && !e) PCT_FAST_PAIR64(1, false, grid1, block1);
             else if (r1) PCT_FAST_PAIR64(1, true, grid1, block1);
@@ -2114,7 +2616,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     const int blocks = (int)((total + 255) / 256);
     hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream,
                        (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->owned_pos.p : nullptr,
-                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
+                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, n_rows, ctx->k, ctx->nbr_pitch, begin, end,
                        d_idx, d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());
@@ -2125,7 +2627,8 @@ int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, 
     const bool sorted = ctx->knn_sorted_space;
     hipLaunchKernelGGL(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
                        (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->row_of.p : nullptr,
-                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
+                       sorted ? (const int*)ctx->owned_pos.p : nullptr,
+                       (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, ctx->k, ctx->nbr_pitch, d_rows, d_idx,
                        d_dist, d_cnt);
     PCT_HIP(ctx, hipGetLastError());

@@ -6,7 +6,7 @@ for d in sys.argv[1:]:
         per_dispatch = collections.defaultdict(float)
         for row in csv.DictReader(open(f)):
             name = row["Kernel_Name"]
-            short = next((s for s in ("k_knn_fast", "k_knn_exact", "k_fit_svd", "k_fit", "k_hist", "k_scatter", "k_pack") if s in name), None)
+            short = next((s for s in ("k_knn_pair", "k_knn_fast", "k_knn_exact", "k_fit_svd", "k_fit", "k_hist", "k_scatter", "k_pack") if s in name), None)
             if short is None:
                 continue
             per_dispatch[(short, row["Dispatch_Id"], row["Counter_Name"])] += float(row["Counter_Value"])
