@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpct_hip.so")
+LIB_PATH = os.environ.get("PCT_LIB") or os.path.join(_HERE, "libpct_hip.so")     # PCT_LIB: a developer's A/B build (tools/build_variant.py)
 
 PCT_OK = 0
 PCT_ERR_HIP = 1

@@ -1741,7 +1741,10 @@ __global__ __launch_bounds__(64 * kFastWaves<R>, (TREE ? (R == 1 ? (PCT_TREE_CAP
 // Staged batches are used in pairs (128 slots); the body is compiled per number of pairs in use, without guards
 // (1 | 2 | 3 | 4): slots of a staged pair beyond the stencil's population sit at +inf.
 // ---------------------------------------------------------------------------
-#include "pct_sort_pair.inc"
+#ifndef PCT_SORT_INC
+#define PCT_SORT_INC "pct_sort_pair.inc"
+#endif
+#include PCT_SORT_INC
 
 __device__ __forceinline__ void sort_pair_asm(unsigned& ea, unsigned& eb, const SortLanes& c) {
     unsigned ta, tb;
@@ -1783,13 +1786,21 @@ struct PairLds {
     int offc[16];                                        // sorted position - flat slot, per non-empty run
 };
 
+#ifndef PCT_PAIR_WAVES
+#define PCT_PAIR_WAVES 1
+#endif
+// waves (= work items) per block; they share nothing but the launch.  One: a finished wave's slot and LDS go to the
+// next block at once (items differ in queries and in staged batches: with four waves per block the fastest three
+// waited for the slowest, 4.6 of 6 wave slots per SIMD filled; 0.392 -> 0.379 ms)
+constexpr int kPairWaves = PCT_PAIR_WAVES;
+
 template <bool EPS, bool DIST>
-__global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
+__global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
     constexpr int CAP = kPairCap, LIST = 64, SLOT_BITS = 6, KEY_BITS = 32 - SLOT_BITS;
-    __shared__ PairLds s_lds[4];
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    __shared__ PairLds s_lds[kPairWaves];
+    const int w = kPairWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
-    const int item = (int)blockIdx.x * 4 + w;
+    const int item = (int)blockIdx.x * kPairWaves + w;
     if (item >= a.n_items) return;
     PairLds& L = s_lds[w];
     const SortLanes sort_dir = make_sort_lanes();
@@ -1845,10 +1856,10 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
         return;
     }
 
-    // ---- copy the runs as one flat range (see k_knn_fast): run starts as a bit string in the list area, run index of
-    // this lane's slots in 4 bits per batch (run_code), offc[u] = sorted position - flat slot of run u
-    unsigned run_code = 0u;
-    static_assert(CAP / 64 <= 8, "run_code holds eight batches");
+    // ---- copy the runs as one flat range (see k_knn_fast): run starts as a bit string in the list area; the run index
+    // u of this lane's slot of batch b rides in the slot id itself (slotx[b] = slot | u << 9: what the compaction
+    // writes into the survivors' lists), offc[u] = sorted position - flat slot of run u
+    unsigned slotx[CAP / 64];
     {
         unsigned* bits = L.pend;
         if (lane < CAP / 32) bits[lane] = 0u;
@@ -1865,6 +1876,7 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
 #pragma unroll
         for (int b = 0; b < CAP / 64; ++b) {
             tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            slotx[b] = (unsigned)(b * 64 + lane);
             if (b * 64 < m) {
                 const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b]);
                 const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b + 1]);
@@ -1874,7 +1886,7 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
                 const int u = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(S >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)S, (unsigned)s0));
                 ubase += (int)__popcll(B);
                 const int j = b * 64 + lane;
-                run_code |= (unsigned)u << (4 * b);
+                slotx[b] |= (unsigned)u << 9;
                 if (j < m) tmp[b] = a.pts[j + L.offc[u]];
             }
         }
@@ -1917,11 +1929,9 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
     const unsigned lane_off = (unsigned)(lane - 1) * 4u;
     const unsigned pitch4 = (unsigned)a.pitch * 4u;
     const bool col_lane = lane >= 1 && lane <= k;         // lanes whose list entry is a table column
+    const unsigned long long first_k1 = (2ull << k) - 1ull;          // lanes 0 .. k: the entries whose order matters
 
-    const auto slot_to_pos = [&](int j) {
-        const unsigned code = (unsigned)__builtin_amdgcn_ds_bpermute((j & 63) << 2, (int)run_code);
-        return j + L.offc[(code >> (((unsigned)j >> 6) << 2)) & 15u];
-    };
+    static_assert(CAP == 512, "slot ids: 9 bits of slot, 4 bits of run index");
 
     const auto pair_loop = [&](auto NBP_) {
         constexpr int NBP = decltype(NBP_)::value, NBU = 2 * NBP;
@@ -1974,6 +1984,10 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
             int cnt_a = tot_a, cnt_b = tot_b;
             bool ok_a = true, ok_b = live_b;
             unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;     // exact keys of the candidates the pre-selection cut are >= bkey
+#ifdef PCT_ABL_NO_TRIAL
+            T_a = T_b = 0.33f * cell2f; cnt_a = cnt_b = 57;
+            if (false)
+#endif
             if (need_a || need_b) {
                 const float target = 0.5f * (float)(k + 1 + LIST);
                 float t0 = t_prev_f > 0.f ? t_prev_f : cell2f;
@@ -1993,15 +2007,18 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
                         c_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < tb));
                     }
                     const int c = lane == 0 ? c_a : c_b;
-                    const bool in = go && c >= k + 1 && c <= LIST;
+                    const bool in = go && (unsigned)(c - (k + 1)) <= (unsigned)(LIST - (k + 1));
                     v_T = in ? v_t : v_T;
                     v_cnt = in ? c : v_cnt;
                     found = found || in;
                     go = go && !in;
+                    if ((__builtin_amdgcn_ballot_w64(go) & 3ull) == 0ull) break;      // both thresholds found: no secant step
+                    // secant step for the lanes still searching (count ~ linear in d^2 on a surface); c = 0 gives +inf,
+                    // which the interval test below turns into a doubling / a bisection
                     const bool below = c < k + 1;
                     v_lo = go && below ? v_t : v_lo;
                     v_hi = go && !below ? v_t : v_hi;
-                    float nt = c > 0 ? v_t * target * __builtin_amdgcn_rcpf((float)c) : 4.f * v_t;
+                    float nt = v_t * target * __builtin_amdgcn_rcpf((float)c);
                     if (!(nt > v_lo && nt < v_hi)) nt = v_hi < INFINITY ? 0.5f * (v_lo + v_hi) : 2.f * v_lo;
                     go = go && nt > v_lo && nt < v_hi;         // no float left between: a pile of equal distances
                     v_t = go ? nt : v_t;
@@ -2034,10 +2051,11 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
                 unsigned wr_a = (unsigned)(uintptr_t)&L.pend[0], wr_b = (unsigned)(uintptr_t)&L.pend_b[0];
                 const unsigned long long all = __builtin_amdgcn_read_exec();
                 wave_lds_sync();
+#ifndef PCT_ABL_NO_COMPACT
 #pragma unroll
                 for (int b = 0; b < NBU; ++b) {
                     unsigned ra, rb, ca, cb;
-                    const unsigned slot = (unsigned)(b * 64 + lane);
+                    const unsigned slot = slotx[b];
                     asm volatile(
                         "v_cmp_gt_f32 vcc, %[ta], %[apa]\n"
                         "v_cmp_gt_f32 s[96:97], %[tb], %[apb]\n"
@@ -2060,15 +2078,21 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
                         : [ta] "v"(T_a), [tb] "v"(T_b), [apa] "v"(ap_a[b]), [apb] "v"(ap_b[b]), [slot] "v"(slot), [all] "s"(all)
                         : "vcc", "scc", "s96", "s97", "memory");
                 }
+#endif
                 wave_lds_sync();
             }
             // ---- exact keys for the survivors only.  Survivor `lane` of each query: staged slot -> coordinates -> fp64
             // ((dx^2 + dy^2) + dz^2) (no FMA: SciPy's value) -> key, distance, sorted position; worked out by every lane
             // (a stale list entry is masked into the staging area and gives a garbage value nobody uses).
-            const int ja = (int)L.pend[lane] & (CAP - 1), jb = (int)L.pend_b[lane] & (CAP - 1);
-            const int out_pa = slot_to_pos(ja), out_pb = slot_to_pos(jb);
+            const unsigned sxa = L.pend[lane] & 0x1FFFu, sxb = (unsigned)L.pend_b[lane] & 0x1FFFu;      // slot | run << 9
+            const int ja = (int)(sxa & (CAP - 1)), jb = (int)(sxb & (CAP - 1));
+            const int out_pa = ja + L.offc[sxa >> 9], out_pb = jb + L.offc[sxb >> 9];                   // sorted positions
             float out_da = 0.f, out_db = 0.f;
             unsigned e_a, e_b;
+#ifdef PCT_ABL_NO_KEYS
+            e_a = ((unsigned)ja << 6) | (unsigned)lane; e_b = ((unsigned)jb << 6) | (unsigned)lane;
+            if (false)
+#endif
             {
                 const double dxa = (double)L.cx[ja] - (double)ax, dya = (double)L.cy[ja] - (double)ay, dza = (double)L.cz[ja] - (double)az;
                 const double dxb = (double)L.cx[jb] - (double)bx, dyb = (double)L.cy[jb] - (double)by, dzb = (double)L.cz[jb] - (double)bz;
@@ -2084,7 +2108,9 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
                 e_b = lane < cnt_b && (!EPS || d2b < eps2) ? kb : kPadElem;
             }
             wave_lds_sync();
+#ifndef PCT_ABL_NO_SORT
             sort_pair_asm(e_a, e_b, sort_dir);
+#endif
             // ---- proof obligations per query (all in key units, see k_knn_fast) ------------------------------------
             const unsigned tau_a = (unsigned)__builtin_amdgcn_readlane((int)e_a, k);      // the (k+1)-th nearest (padding if fewer exist)
             const unsigned tau_b = (unsigned)__builtin_amdgcn_readlane((int)e_b, k);
@@ -2095,15 +2121,28 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
             const unsigned need_kb = min(tau_b == kPadElem ? 0xFFFFFFFFu : tk_b + 1u, eps_key);
             const bool amb_a = need_ka > min(g_a, bkey_a) || (tau_a != kPadElem && tk_a >= key_max - 1u);
             const bool amb_b = need_kb > min(g_b, bkey_b) || (tau_b != kPadElem && tk_b >= key_max - 1u);
+#ifndef PCT_ABL_NO_CHECK
             if (ok_a && amb_a) { redo_mask |= 1ull << qi; ok_a = false; }
             if (ok_b && amb_b) { redo_mask |= 1ull << qj; ok_b = false; }
-            // equal keys among the first k+2 entries: ordered here by the exact values (order_equal_keys)
+#endif
+            // equal keys among the first k+2 entries: ordered here by the exact values (order_equal_keys).  Detection:
+            // element i ^ element i+1 (one v_xor with a wave_shl:1 operand per set) below 64 <=> same key
             {
-                const unsigned up_a = (unsigned)__builtin_amdgcn_update_dpp((int)kPadElem, (int)e_a, 0x130, 0xF, 0xF, false);   // wave_shl:1 = element i + 1
-                const unsigned up_b = (unsigned)__builtin_amdgcn_update_dpp((int)kPadElem, (int)e_b, 0x130, 0xF, 0xF, false);
-                const bool col_a = lane <= k && up_a != kPadElem && ((e_a ^ up_a) >> SLOT_BITS) == 0u;     // (a real element sorts below padding)
-                const bool col_b = lane <= k && up_b != kPadElem && ((e_b ^ up_b) >> SLOT_BITS) == 0u;
-                const unsigned long long cm_a = __builtin_amdgcn_ballot_w64(col_a), cm_b = __builtin_amdgcn_ballot_w64(col_b);
+                unsigned xa, xb;
+                asm("v_xor_b32_dpp %0, %2, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                    "v_xor_b32_dpp %1, %3, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                    "s_nop 0"
+                    : "=&v"(xa), "=&v"(xb) : "v"(e_a), "v"(e_b));
+#ifdef PCT_ABL_NO_CHECK
+                const unsigned long long cm_any = 0ull;
+#else
+                const unsigned long long cm_any = __builtin_amdgcn_ballot_w64(min(xa, xb) < 64u) & first_k1;
+#endif
+                unsigned long long cm_a = 0ull, cm_b = 0ull;
+                if (__builtin_expect(cm_any != 0ull, 0)) {
+                    cm_a = __builtin_amdgcn_ballot_w64(xa < 64u && e_a != kPadElem) & first_k1;
+                    cm_b = __builtin_amdgcn_ballot_w64(xb < 64u && e_b != kPadElem) & first_k1;
+                }
                 if (__builtin_expect((cm_a | cm_b) != 0ull, 0)) {
                     if (ok_a && cm_a != 0ull) {
                         const double ux = (double)ax, uy = (double)ay, uz = (double)az;
@@ -2133,17 +2172,23 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
             {
                 const unsigned off_a = lane_off + (unsigned)qi * pitch4, off_b = lane_off + (unsigned)qj * pitch4;
                 const bool real_a = e_a != kPadElem, real_b = e_b != kPadElem;
-                const int at_a = (int)(e_a & 63u) << 2, at_b = (int)(e_b & 63u) << 2;
+                const int at_a = (int)(e_a << 2), at_b = (int)(e_b << 2);        // ds_bpermute reads lane (address >> 2) & 63: the survivor index
                 const int pos_a = __builtin_amdgcn_ds_bpermute(at_a, out_pa), pos_b = __builtin_amdgcn_ds_bpermute(at_b, out_pb);
                 float dist_a = 0.f, dist_b = 0.f;
                 if constexpr (DIST) {
                     dist_a = __int_as_float(__builtin_amdgcn_ds_bpermute(at_a, __float_as_int(out_da)));
                     dist_b = __int_as_float(__builtin_amdgcn_ds_bpermute(at_b, __float_as_int(out_db)));
                 }
+#ifdef PCT_ABL_NO_STORE
+                if (pos_a == 0x7fffffff && pos_b == 0x7ffffff1)
+#endif
                 if (ok_a && col_lane) {
                     *(int*)(pos_item + off_a) = real_a ? pos_a : -1;
                     if constexpr (DIST) *(float*)(dist_item + off_a) = real_a ? dist_a : INFINITY;
                 }
+#ifdef PCT_ABL_NO_STORE
+                if (pos_a == 0x7fffffff && pos_b == 0x7ffffff1)
+#endif
                 if (ok_b && col_lane) {
                     *(int*)(pos_item + off_b) = real_b ? pos_b : -1;
                     if constexpr (DIST) *(float*)(dist_item + off_b) = real_b ? dist_b : INFINITY;
@@ -2167,6 +2212,9 @@ __global__ __launch_bounds__(256, 6) void k_knn_pair(PairArgs a) {
         else if (nbp == 3) pair_loop(integral_constant<int, (CAP >= 384 ? 3 : 1)>{});
         else pair_loop(integral_constant<int, (CAP >= 512 ? 4 : 1)>{});
     }
+#if defined(PCT_ABL_NO_SORT) || defined(PCT_ABL_NO_COMPACT) || defined(PCT_ABL_NO_KEYS) || defined(PCT_ABL_NO_TRIAL) || defined(PCT_ABL_NO_STORE) || defined(PCT_ABL_NO_CHECK)
+    redo_mask = 0ull;          // timing experiments: nothing goes to the exact sweep
+#endif
     if (redo_mask) {
         const int cnt = (int)__popcll(redo_mask);
         int base = 0;
@@ -2479,10 +2527,11 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             };
             magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
             magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
-            if (e && skip_dist) hipLaunchKernelGGL((k_knn_pair<true, false>), grid1, block1, 0, ctx->stream, pa);
-            else if (e) hipLaunchKernelGGL((k_knn_pair<true, true>), grid1, block1, 0, ctx->stream, pa);
-            else if (skip_dist) hipLaunchKernelGGL((k_knn_pair<false, false>), grid1, block1, 0, ctx->stream, pa);
-            else hipLaunchKernelGGL((k_knn_pair<false, true>), grid1, block1, 0, ctx->stream, pa);
+            const dim3 gridp((unsigned)((ctx->n_items + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
+            if (e && skip_dist) hipLaunchKernelGGL((k_knn_pair<true, false>), gridp, blockp, 0, ctx->stream, pa);
+            else if (e) hipLaunchKernelGGL((k_knn_pair<true, true>), gridp, blockp, 0, ctx->stream, pa);
+            else if (skip_dist) hipLaunchKernelGGL((k_knn_pair<false, false>), gridp, blockp, 0, ctx->stream, pa);
+            else hipLaunchKernelGGL((k_knn_pair<false, true>), gridp, blockp, 0, ctx->stream, pa);
         } else
         if (q64_ok && !no_pair) {
             if (r1 && !e) PCT_FAST_PAIR64(1, false, grid1, block1);

@@ -42,7 +42,7 @@ class Gen:
 DPP_CTRL = {1: "quad_perm:[1,0,3,2]", 2: "quad_perm:[2,3,0,1]", 8: "row_ror:8"}
 FLIP_CTRL = {2: "quad_perm:[1,0,3,2]", 4: "quad_perm:[3,2,1,0]", 8: "row_half_mirror", 16: "row_mirror"}
 
-def network(sets=("a", "b")):
+def network(sets=("a", "b"), swz=()):
     g = Gen()
     cur = {s: "e" + s for s in sets}      # register holding the set's elements
     tmp = {s: "t" + s for s in sets}
@@ -85,9 +85,24 @@ def network(sets=("a", "b")):
             g.emit(f"s_waitcnt lgkmcnt({len(sets) - 1 - i})")
             g.emit(f"v_med3_u32 {e}, {e}, {t}, {R(sel)}", writes=[e])
 
+    def swizzle_level(xor, sel):
+        # partner move on the LDS pipe (ds_swizzle, bit mode: lane ^ xor inside 32 lanes): no VALU slot, ~2 LDS cycles
+        for s in sets:
+            e, t = R(cur[s]), R(tmp[s])
+            g.emit(f"ds_swizzle_b32 {t}, {e} offset:0x{0x1f | (xor << 10):04x}")
+        for i, s in enumerate(sets):
+            e, t = R(cur[s]), R(tmp[s])
+            g.emit(f"s_waitcnt lgkmcnt({len(sets) - 1 - i})")
+            g.emit(f"v_med3_u32 {e}, {e}, {t}, {R(sel)}", writes=[e])
+
+    level_no = [0]
+
     def stride(st):
         sel = "sel%d" % (st.bit_length() - 1)
-        if st == 4:
+        level_no[0] += 1
+        if level_no[0] in swz:
+            swizzle_level(st, sel)
+        elif st == 4:
             xor4_level()
         elif st == 16:
             swap16_level(sel)
@@ -97,7 +112,10 @@ def network(sets=("a", "b")):
     size = 2
     while size <= 64:
         sel = "sel%d" % (size.bit_length() - 2)
-        if size <= 16:
+        level_no[0] += 1
+        if level_no[0] in swz and size <= 32:
+            swizzle_level(size - 1, sel)
+        elif size <= 16:
             dpp_level(FLIP_CTRL[size], sel)
         else:
             bperm_level("a31" if size == 32 else "a63", sel)
@@ -110,8 +128,10 @@ def network(sets=("a", "b")):
     return g.out, cur
 
 if __name__ == "__main__":
-    lines, cur = network()
-    print("// generated by tools/gen_sort_asm.py -- do not edit")
+    # levels (1..21 in network order) whose partner move goes through ds_swizzle instead of DPP / permlane / bpermute
+    swz = set(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 and sys.argv[1] else set()
+    lines, cur = network(swz=swz)
+    print("// generated by tools/gen_sort_asm.py %s -- do not edit" % " ".join(sys.argv[1:]))
     print("// result registers: set a in %%[%s], set b in %%[%s]" % (cur["a"], cur["b"]))
     print("#define PCT_SORT_PAIR_RESULT_A %s" % cur["a"])
     print("#define PCT_SORT_PAIR_RESULT_B %s" % cur["b"])
@@ -121,4 +141,4 @@ if __name__ == "__main__":
     print('    ""')
     n_valu = sum(1 for l in lines if l.startswith("v_"))
     n_nop = sum(1 for l in lines if l.startswith("s_nop"))
-    print("// %d VALU, %d s_nop, %d ds_bpermute" % (n_valu, n_nop, sum(1 for l in lines if l.startswith("ds_"))))
+    print("// %d VALU, %d s_nop, %d ds_bpermute, %d ds_swizzle" % (n_valu, n_nop, sum(1 for l in lines if l.startswith("ds_bperm")), sum(1 for l in lines if l.startswith("ds_swizzle"))))

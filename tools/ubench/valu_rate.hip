@@ -56,6 +56,19 @@ KERNEL(k_mbcnt, "v_mbcnt_lo_u32_b32 %0, %4, %0\n v_mbcnt_hi_u32_b32 %1, %4, %1\n
 KERNEL(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %4\n v_lshl_add_u32 %1, %1, 2, %4\n v_cndmask_b32 %2, %2, %4, vcc\n v_add_u32 %3, %3, %4\n",
        : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ub) : "vcc")
 
+KERNEL(k_swizzle, "ds_swizzle_b32 %0, %0 offset:0x041f\n ds_swizzle_b32 %1, %1 offset:0x081f\n ds_swizzle_b32 %2, %2 offset:0x101f\n ds_swizzle_b32 %3, %3 offset:0x201f\n s_waitcnt lgkmcnt(0)\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3))
+KERNEL(k_bperm, "ds_bpermute_b32 %0, %4, %0\n ds_bpermute_b32 %1, %4, %1\n ds_bpermute_b32 %2, %4, %2\n ds_bpermute_b32 %3, %4, %3\n s_waitcnt lgkmcnt(0)\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ub))
+KERNEL(k_swz_med3, "ds_swizzle_b32 %2, %0 offset:0x041f\n ds_swizzle_b32 %3, %1 offset:0x041f\n s_waitcnt lgkmcnt(1)\n v_med3_u32 %0, %0, %2, %4\n s_waitcnt lgkmcnt(0)\n v_med3_u32 %1, %1, %3, %4\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ub))
+KERNEL(k_dpp_med3, "v_mov_b32_dpp %2, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_med3_u32 %0, %0, %2, %4\n v_mov_b32_dpp %3, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n v_med3_u32 %1, %1, %3, %4\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ub))
+KERNEL(k_permlane32, "v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3))
+KERNEL(k_valu_lds_mix, "ds_swizzle_b32 %2, %0 offset:0x041f\n v_med3_u32 %0, %0, %4, %1\n v_med3_u32 %1, %1, %4, %0\n v_med3_u32 %3, %3, %4, %1\n s_waitcnt lgkmcnt(0)\n",
+       : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3) : "v"(ub))
+
 template <class K>
 int run(const char* name, K kern, int n_instr_per_body) {
     float* out; long long* cyc;
@@ -100,6 +113,12 @@ int main() {
     run("readlane", k_readlane, 4);
     run("mbcnt", k_mbcnt, 4);
     run("int misc", k_lshl_or, 4);
+    run("ds_swizzle", k_swizzle, 4);
+    run("ds_bpermute", k_bperm, 4);
+    run("swz+med3 x2", k_swz_med3, 4);
+    run("dpp+med3 x2", k_dpp_med3, 4);
+    run("permlane swap", k_permlane32, 4);
+    run("1swz+3med3", k_valu_lds_mix, 4);
     // wall-clock calibration of the tick
     float* out; long long* cyc;
     hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 8);
