@@ -374,10 +374,23 @@ def main():
         achieved = algo_bytes / knn_avg_s / 1e9
         traffic, traffic_source = measured_traffic(nq, k)
         par = f"point-index-range shards x{world}"
+        issued = None
         if dist_mode:
-            par += (" + RCCL all-gather of the float32 coordinates over xGMI (ncclAllGather called from libpct_hip.so on the handle's "
-                    "exchange stream, no PyTorch in the process; double-buffered, overlapped with the previous pass), each rank keeps "
-                    "the points near its range")
+            issued = handle.comm_counters()
+            forms = []
+            if issued["allgather"]:
+                forms.append(f"{issued['allgather']} x ncclAllGather straight into the gather buffer")
+            if issued["padded_allgather"]:
+                forms.append(f"{issued['padded_allgather']} x ncclAllGather of shards padded to the largest + compaction pass")
+            if issued["broadcast_groups"]:
+                forms.append(f"{issued['broadcast_groups']} x group of per-rank ncclBroadcast")
+            if forms:
+                par += (" + RCCL exchange of the float32 coordinates over xGMI, called from libpct_hip.so on the handle's exchange "
+                        "stream (" + "; ".join(forms) + "; no PyTorch in the process; double-buffered, overlapped with the previous "
+                        "pass), each rank keeps the points near its range")
+            else:
+                par += (" -- multi-GPU driver with a world of one rank: communicator and buffers set up, no collective issued "
+                        "(PCT_COMM_FORCE=allgather|padded|bcast issues one per step)")
         out = {
             "metric": "points/sec curvature (1M-pt torus, k=50); HBM GB/s k-NN vs peak",
             "value": n_total * steps / dt,
@@ -390,7 +403,8 @@ def main():
                                    + (f"{args.points_per_gpu} points per GPU ({n_total} total)" if weak else f"{n_total} points in all")
                                    + f", k={k}" + (f", eps={eps}" if eps else "") + ", grid k-NN + fused plane-align/quadric-fit/curvature "
                                    f"({cfg['base']})",
-                       "points_total": n_total, "k": k, "parallelism": par},
+                       "points_total": n_total, "k": k, "parallelism": par,
+                       **({"collectives_issued": issued} if issued is not None else {})},
             "roofline": {"bound": "hbm", "kernel": "k_knn_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_ms / steps},

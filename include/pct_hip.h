@@ -229,8 +229,14 @@ int pct_comm_unique_id(void* id128);
 int pct_comm_init(pct_ctx* ctx, int32_t rank, int32_t world, const void* id128);
 int pct_comm_destroy(pct_ctx* ctx);
 /* Rank r contributes counts[r] floats at dev_send; dev_recv receives all shards back to back in rank order.
- * Asynchronous: runs on the handle's exchange stream, ordered after the work the compute stream holds at the call. */
+ * Asynchronous: runs on the handle's exchange stream, ordered after the work the compute stream holds at the call.
+ * One exchange in flight per handle: a second call before pct_comm_wait / pct_comm_synchronize is PCT_ERR_INVALID.
+ * Equal shards: ncclAllGather into dev_recv; unequal ones (zero-sized too): shards padded to the largest, one
+ * ncclAllGather, one compaction pass.  PCT_COMM_FORCE=allgather|padded|bcast (environment) picks the form. */
 int pct_comm_allgather_f32(pct_ctx* ctx, const void* dev_send, void* dev_recv, const int64_t* counts);
+/* Collectives issued so far by this handle: out4 = {ncclAllGather in place, padded ncclAllGather + compaction, groups
+ * of per-rank ncclBroadcast, ncclAllReduce}. */
+int pct_comm_counters(pct_ctx* ctx, int64_t* out4);
 /* The compute stream waits for the last exchange on the device (the host does not block) ... */
 int pct_comm_wait(pct_ctx* ctx);
 /* ... or the host does. */

@@ -90,6 +90,7 @@ SIGNATURES = {
     "pct_comm_init": (C.c_int, [_p, C.c_int32, C.c_int32, _p]),
     "pct_comm_destroy": (C.c_int, [_p]),
     "pct_comm_allgather_f32": (C.c_int, [_p, _p, _p, _i64p]),
+    "pct_comm_counters": (C.c_int, [_p, _i64p]),
     "pct_comm_wait": (C.c_int, [_p]),
     "pct_comm_synchronize": (C.c_int, [_p]),
     "pct_comm_allreduce_f64": (C.c_int, [_p, _f64p, C.c_int32, C.c_int32]),
@@ -414,6 +415,12 @@ class Handle:
         """Start the all-gather of float32 shards (counts[r] floats from rank r) on the exchange stream."""
         c = np.ascontiguousarray(counts, dtype=np.int64)
         self._check(self._lib.pct_comm_allgather_f32(self._h, _p(int(dev_send)), _p(int(dev_recv)), _ptr(c, _i64p)))
+
+    def comm_counters(self):
+        """Collectives issued by this handle: {allgather, padded_allgather, broadcast_groups, allreduce}."""
+        c = np.zeros(4, np.int64)
+        self._check(self._lib.pct_comm_counters(self._h, _ptr(c, _i64p)))
+        return dict(zip(("allgather", "padded_allgather", "broadcast_groups", "allreduce"), (int(v) for v in c)))
 
     def comm_wait(self):
         self._check(self._lib.pct_comm_wait(self._h))

@@ -17,7 +17,12 @@ struct pct_comm {
     int rank = 0, world = 1;
     hipStream_t stream = nullptr;      // the exchange runs here, beside the handle's compute stream
     hipEvent_t done = nullptr, ready = nullptr;
+    bool in_flight = false;            // an exchange has been enqueued and nobody has waited for it yet (one `done` event)
     void* scratch = nullptr;           // 64 B of device memory for the scalar reductions
+    void* padded = nullptr;            // world x max(counts) floats: receive buffer of the padded all-gather (unequal shards)
+    size_t padded_cap = 0;
+    int64_t issued[4] = {0, 0, 0, 0};  // collectives issued: [0] ncclAllGather in place, [1] padded ncclAllGather + compaction,
+                                       // [2] groups of per-rank ncclBroadcast, [3] ncclAllReduce
     ncclResult_t (*InitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*Destroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
@@ -52,6 +57,19 @@ bool sym(void* lib, const char* name, F* out) {
             return pct_fail((ctx), PCT_ERR_HIP, "%s failed: %s", #call, (c)->ErrorString ? (c)->ErrorString(r_) : "?"); \
     } while (0)
 
+// padded all-gather -> back-to-back shards: rank r's slot holds counts[r] floats at r * pitch; off[r] = its place
+// in the gathered array (off[world] = total).  One pass, 16 B per lane where the alignment allows.
+struct ShardOffsets { int64_t v[65]; };
+__global__ __launch_bounds__(256) void k_unpad(const float* __restrict__ padded, int64_t pitch, ShardOffsets off,
+                                               int world, float* __restrict__ out) {
+    const int r = blockIdx.y;
+    if (r >= world) return;
+    const int64_t n = off.v[r + 1] - off.v[r];
+    const float* src = padded + (int64_t)r * pitch;
+    float* dst = out + off.v[r];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 int need_comm(pct_ctx* ctx) {
     if (!ctx) return PCT_ERR_INVALID;
     ctx->err[0] = 0;
@@ -68,6 +86,7 @@ void pct_comm_release(pct_ctx* ctx) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->comm && c->Destroy) (void)c->Destroy(c->comm);
     if (c->scratch) (void)hipFree(c->scratch);
+    if (c->padded) (void)hipFree(c->padded);
     if (c->done) (void)hipEventDestroy(c->done);
     if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -137,43 +156,98 @@ int pct_comm_destroy(pct_ctx* ctx) {
 
 // All-gather of float32 shards: rank r contributes counts[r] floats from dev_send, dev_recv receives them back to
 // back in rank order.  Asynchronous: enqueued on the exchange stream, which first waits for what the compute stream
-// has been given so far (a buffer the previous pass still reads is not overwritten under it).
+// has been given so far (a buffer the previous pass still reads is not overwritten under it).  ONE exchange may be in
+// flight per handle (one completion event): a second call before pct_comm_wait / pct_comm_synchronize is refused.
+// Equal shards: ncclAllGather straight into dev_recv.  Unequal shards (C5's 20 022 479 points over 8 ranks; a cloud
+// smaller than the world leaves ranks with nothing): every shard padded to the largest -- one ncclAllGather into a
+// scratch buffer, one compaction pass (k_unpad) -- the standard form, one collective whatever the sizes.
+// PCT_COMM_FORCE = allgather | padded | bcast picks the form regardless (bcast: one ncclBroadcast per non-empty rank
+// inside a group; kept as an alternative and exercised by the tests), so that every form can be run with one rank.
 int pct_comm_allgather_f32(pct_ctx* ctx, const void* dev_send, void* dev_recv, const int64_t* counts) {
     PCT_TRY(need_comm(ctx));
     pct_comm* c = ctx->comm;
     if (!dev_send || !dev_recv || !counts) return pct_fail(ctx, PCT_ERR_INVALID, "null exchange buffer");
+    if (c->in_flight) return pct_fail(ctx, PCT_ERR_INVALID, "an exchange is already in flight on this handle: pct_comm_wait first");
     bool equal = true;
+    int64_t most = 0, total = 0;
     for (int r = 0; r < c->world; ++r) {
         if (counts[r] < 0) return pct_fail(ctx, PCT_ERR_INVALID, "negative shard size");
         equal = equal && counts[r] == counts[0];
+        most = counts[r] > most ? counts[r] : most;
+        total += counts[r];
     }
+    enum { AG = 0, PADDED = 1, BCAST = 2 };
+    int mode = equal ? AG : PADDED;
+    if (const char* f = getenv("PCT_COMM_FORCE")) {
+        if (!strcmp(f, "bcast")) mode = BCAST;
+        else if (!strcmp(f, "padded")) mode = PADDED;
+        else if (!strcmp(f, "allgather") && equal) mode = AG;
+    }
+    if (total == 0) return PCT_OK;                         // nothing to move (and nothing to wait for)
     PCT_HIP(ctx, hipEventRecord(c->ready, ctx->stream));
     PCT_HIP(ctx, hipStreamWaitEvent(c->stream, c->ready, 0));
-    if (equal) {
+    if (mode == AG) {
         PCT_NCCL(ctx, c, c->AllGather(dev_send, dev_recv, (size_t)counts[0], ncclFloat32, c->comm, c->stream));
+    } else if (mode == PADDED) {
+        if (c->world > 64) return pct_fail(ctx, PCT_ERR_INVALID, "more than 64 ranks");
+        const size_t need = (size_t)c->world * (size_t)most * sizeof(float);
+        if (need > c->padded_cap) {
+            PCT_HIP(ctx, hipStreamSynchronize(c->stream));
+            if (c->padded) (void)hipFree(c->padded);
+            c->padded = nullptr; c->padded_cap = 0;
+            PCT_HIP(ctx, hipMalloc(&c->padded, need + need / 8));
+            c->padded_cap = need + need / 8;
+        }
+        ShardOffsets off;
+        off.v[0] = 0;
+        for (int r = 0; r < c->world; ++r) off.v[r + 1] = off.v[r] + counts[r];
+        // my shard into my slot is the collective's job too: ncclAllGather reads `most` floats from the send buffer, so
+        // the send side goes through the slot (a shard shorter than the largest must not be read past its end)
+        float* mine = (float*)c->padded + (size_t)c->rank * (size_t)most;
+        if (counts[c->rank] > 0)
+            PCT_HIP(ctx, hipMemcpyAsync(mine, dev_send, (size_t)counts[c->rank] * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
+        PCT_NCCL(ctx, c, c->AllGather(mine, c->padded, (size_t)most, ncclFloat32, c->comm, c->stream));
+        const int bx = (int)((most + 255) / 256 < 2048 ? (most + 255) / 256 : 2048);
+        hipLaunchKernelGGL(k_unpad, dim3(bx > 0 ? bx : 1, c->world), dim3(256), 0, c->stream, (const float*)c->padded, most,
+                           off, c->world, (float*)dev_recv);
+        PCT_HIP(ctx, hipGetLastError());
     } else {
-        // shards of different sizes: one broadcast per rank, fused by the group
+        // one broadcast per rank that has something, fused by the group
         PCT_NCCL(ctx, c, c->GroupStart());
         int64_t off = 0;
         for (int r = 0; r < c->world; ++r) {
             float* dst = (float*)dev_recv + off;
-            const ncclResult_t rr = c->Broadcast(r == c->rank ? dev_send : (const void*)dst, dst, (size_t)counts[r], ncclFloat32, r, c->comm, c->stream);
-            if (rr != ncclSuccess) {
-                (void)c->GroupEnd();
-                return pct_fail(ctx, PCT_ERR_HIP, "ncclBroadcast failed: %s", c->ErrorString(rr));
+            if (counts[r] > 0) {
+                const ncclResult_t rr = c->Broadcast(r == c->rank ? dev_send : (const void*)dst, dst, (size_t)counts[r], ncclFloat32, r, c->comm, c->stream);
+                if (rr != ncclSuccess) {
+                    (void)c->GroupEnd();
+                    return pct_fail(ctx, PCT_ERR_HIP, "ncclBroadcast failed: %s", c->ErrorString(rr));
+                }
             }
             off += counts[r];
         }
         PCT_NCCL(ctx, c, c->GroupEnd());
     }
+    ++c->issued[mode];
     PCT_HIP(ctx, hipEventRecord(c->done, c->stream));
+    c->in_flight = true;
+    return PCT_OK;
+}
+
+// Collectives this handle has issued so far: out4 = {ncclAllGather straight into the receive buffer, padded
+// ncclAllGather + compaction, groups of per-rank ncclBroadcast, ncclAllReduce} -- what a report may claim.
+int pct_comm_counters(pct_ctx* ctx, int64_t* out4) {
+    PCT_TRY(need_comm(ctx));
+    if (!out4) return pct_fail(ctx, PCT_ERR_INVALID, "null output");
+    memcpy(out4, ctx->comm->issued, sizeof(ctx->comm->issued));
     return PCT_OK;
 }
 
 // The compute stream waits (on the device, the host does not block) for the last exchange.
 int pct_comm_wait(pct_ctx* ctx) {
     PCT_TRY(need_comm(ctx));
-    PCT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->done, 0));
+    if (ctx->comm->in_flight) PCT_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->comm->done, 0));
+    ctx->comm->in_flight = false;
     return PCT_OK;
 }
 
@@ -181,6 +255,7 @@ int pct_comm_wait(pct_ctx* ctx) {
 int pct_comm_synchronize(pct_ctx* ctx) {
     PCT_TRY(need_comm(ctx));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->comm->stream));
+    ctx->comm->in_flight = false;
     return PCT_OK;
 }
 
@@ -195,6 +270,7 @@ int pct_comm_allreduce_f64(pct_ctx* ctx, double* values, int32_t n, int32_t op) 
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));           // a barrier also means: my kernels are done
     PCT_HIP(ctx, hipMemcpyAsync(c->scratch, tmp, m * sizeof(double), hipMemcpyHostToDevice, c->stream));
     PCT_NCCL(ctx, c, c->AllReduce(c->scratch, c->scratch, (size_t)m, ncclFloat64, (ncclRedOp_t)op, c->comm, c->stream));
+    ++c->issued[3];
     PCT_HIP(ctx, hipMemcpyAsync(tmp, c->scratch, m * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PCT_HIP(ctx, hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; ++i) values[i] = tmp[i];

@@ -56,16 +56,42 @@ def _recv_exact(sock, n):
 RDZV_PORTS = 8          # rank 0 listens on the first free port of MASTER_PORT+1 .. +8; peers probe them in turn
 
 
+def _job_token(addr, port, world):
+    """8 bytes that tell this job's rendezvous from another job's on a neighbouring port: both sides derive them from
+    what the launcher gave every rank of ONE job (MASTER_ADDR : MASTER_PORT, WORLD_SIZE)."""
+    import hashlib
+    base = os.environ.get("MASTER_PORT", str(port))
+    return hashlib.sha256(f"{addr}:{base}:{world}".encode()).digest()[:8]
+
+
+def _is_local(addr):
+    try:
+        ip = socket.gethostbyname(addr)
+    except OSError:
+        return False
+    if ip.startswith("127."):
+        return True
+    try:
+        with socket.socket(socket.AF_INET, socket.SOCK_DGRAM) as s:
+            s.bind((ip, 0))
+        return True
+    except OSError:
+        return False
+
+
 def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180.0):
     """Rank 0 calls ``make_id()`` (128 bytes) and serves them to the other ``world - 1`` ranks; every rank returns the
-    same bytes.  Each peer announces itself (magic, rank) and the answer carries the magic back, so neither a stray
-    connection nor a foreign service on one of the candidate ports can be mistaken for the rendezvous."""
+    same bytes.  Each peer announces itself (magic, rank, job token) and the answer carries magic and token back, so
+    neither a stray connection, nor a foreign service, nor ANOTHER JOB's rendezvous on one of the candidate ports (two
+    jobs on one host whose MASTER_PORTs are within 8 of each other) can be mistaken for this one.  The listener binds
+    to MASTER_ADDR when that is an address of this host."""
     if world == 1:
         return make_id()
     addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
     if port is None:
         port = int(os.environ.get("PCT_RDZV_PORT", "0")) or int(os.environ.get("MASTER_PORT", "29500")) + 1
     ports = [port + i for i in range(RDZV_PORTS)]
+    token = _job_token(addr, port, world)
     deadline = time.monotonic() + timeout
     if rank == 0:
         payload = make_id()
@@ -76,7 +102,7 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
             s = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             s.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             try:
-                s.bind(("", p))
+                s.bind((addr if _is_local(addr) else "", p))
                 s.listen(world)
                 srv = s
                 break
@@ -95,10 +121,10 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
                 with conn:
                     conn.settimeout(10.0)
                     try:
-                        magic, peer = struct.unpack("!4sI", _recv_exact(conn, 8))
-                        if magic != b"PCT1" or not (0 < peer < world) or peer in served:
-                            continue
-                        conn.sendall(b"PCT1" + payload)
+                        magic, peer, tok = struct.unpack("!4sI8s", _recv_exact(conn, 16))
+                        if magic != b"PCT2" or tok != token or not (0 < peer < world) or peer in served:
+                            continue                     # a stray connection, or a rank of another job
+                        conn.sendall(b"PCT2" + token + payload)
                     except (ConnectionError, socket.timeout, struct.error, OSError):
                         continue
                     served.add(peer)
@@ -111,10 +137,10 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
             try:
                 with socket.create_connection((addr, p), timeout=5.0) as s:
                     s.settimeout(10.0)
-                    s.sendall(struct.pack("!4sI", b"PCT1", rank))
-                    answer = _recv_exact(s, 132)
-                    if answer[:4] == b"PCT1":
-                        return answer[4:]
+                    s.sendall(struct.pack("!4sI8s", b"PCT2", rank, token))
+                    answer = _recv_exact(s, 140)
+                    if answer[:4] == b"PCT2" and answer[4:12] == token:      # (another job's listener answers nothing we accept)
+                        return answer[12:]
             except (ConnectionError, socket.timeout, OSError) as e:     # rank 0 is not listening (there) yet
                 last = e
         time.sleep(0.05)
@@ -168,6 +194,9 @@ class ShardedCurvature:
         self.lo, self.hi = shard_range(self.n_total, rank, world)
         self.counts = np.asarray(shard_sizes(self.n_total, world), dtype=np.int64) * 3       # floats per rank
         self._send = self._bufs = None
+        # a world of one rank issues no collective -- unless PCT_COMM_FORCE asks for one (allgather | padded | bcast):
+        # the rehearsal of every form of the exchange on a single GPU
+        self.collective = self.world > 1 or (exchange is not None and compute is None and bool(os.environ.get("PCT_COMM_FORCE")))
         if handle is None and compute is None:
             raise RuntimeError("ShardedCurvature needs a device handle (HIP path); there is no CPU fallback")
         if world > 1 and exchange is None:
@@ -181,7 +210,8 @@ class ShardedCurvature:
             raise ValueError(f"rank {self.rank} must hold rows [{self.lo},{self.hi}) of the cloud, got {local_pts.shape}")
         if self.compute is None:
             self.upload_shard(local_pts)
-            self.run_device(self.end_exchange(self.begin_exchange(0)))
+            self._steps = getattr(self, "_steps", -1) + 1           # consecutive steps alternate the gather buffers
+            self.run_device(self.end_exchange(self.begin_exchange(self._steps)))
             return self.download()
         full = local_pts if self.world == 1 else self.exchange.allgather_host(local_pts, self.counts)
         return self.compute(full, self.lo, self.hi, self.k, self.eps)
@@ -191,7 +221,7 @@ class ShardedCurvature:
         if self._bufs is None:
             h = self.handle
             self._send = h.device_alloc(max(int(self.counts[self.rank]), 1) * 4)
-            self._bufs = [h.device_alloc(self.n_total * 12) for _ in range(2 if self.world > 1 else 1)]
+            self._bufs = [h.device_alloc(max(self.n_total, 1) * 12) for _ in range(2 if self.collective else 1)]
         return self
 
     def upload_shard(self, local_pts):
@@ -200,20 +230,20 @@ class ShardedCurvature:
         local_pts = np.ascontiguousarray(local_pts, dtype=np.float32)
         if local_pts.shape != (self.hi - self.lo, 3):
             raise ValueError(f"rank {self.rank} must hold rows [{self.lo},{self.hi}) of the cloud, got {local_pts.shape}")
-        if self.world > 1:
+        if self.collective:
             self.handle.comm_synchronize()
         if len(local_pts):
-            self.handle.device_upload(self._send if self.world > 1 else self._bufs[0], local_pts)
+            self.handle.device_upload(self._send if self.collective else self._bufs[0], local_pts)
 
     def begin_exchange(self, i):
         """Start the all-gather of the resident shard into gather buffer ``i % 2``; returns a ticket."""
         self.setup_device()
-        if self.world == 1:
+        if not self.collective:
             return self._bufs[0]
         return self.exchange.begin(self._send, self._bufs[i % 2], self.counts)
 
     def end_exchange(self, ticket):
-        if self.world == 1:
+        if not self.collective:
             return ticket
         return self.exchange.end(ticket)
 
@@ -233,7 +263,7 @@ class ShardedCurvature:
         if self._bufs is not None:
             h = self.handle
             h.synchronize()
-            if self.world > 1:
+            if self.collective:
                 h.comm_synchronize()
             for p in [self._send] + self._bufs:
                 h.device_free(p)

@@ -917,29 +917,44 @@ def test_neighbor_study_on_a_plane_converges_low(gpu):
     assert res == ref
 
 
-def test_distributed_step_on_one_rank(gpu, tmp_path):
+@pytest.mark.parametrize("config,force,issued", [("c4", "", None), ("c4", "allgather", "allgather"), ("c4", "bcast", "broadcast_groups"),
+                                                 ("c5", "padded", "padded_allgather")])
+def test_distributed_step_on_one_rank(gpu, tmp_path, config, force, issued):
     """The multi-GPU code path of bench.py -- RCCL communicator behind the C ABI (no PyTorch in the process), unique id
-    through the TCP rendezvous, all-gather into a device buffer on the exchange stream, zero-copy hand-over,
-    owned-range sweep, double-buffered exchange -- with a world of one rank, on BASELINE configs[3] (egg carton 5 M),
-    checked against the sampled reference golden."""
+    through the TCP rendezvous, exchange into a device buffer on the exchange stream, zero-copy hand-over, owned-range
+    sweep, double-buffered exchange -- with a world of one rank, on BASELINE configs[3] (egg carton 5 M) and configs[4]
+    (bunny x 557, 20 M points, k = 80, eps), checked against the sampled reference goldens.  With one rank and no
+    PCT_COMM_FORCE the driver has nothing to exchange and issues no collective (the line says so); PCT_COMM_FORCE makes
+    it issue the real thing inside every step: ncclAllGather straight into the gather buffer, the group of per-rank
+    ncclBroadcast, and the padded ncclAllGather + compaction that unequal shards take (C5 over 8 ranks)."""
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, PCT_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    for v in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "PCT_COMM_FORCE"):
         env.pop(v, None)
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--config", "c4", "--verify",
+    if force:
+        env["PCT_COMM_FORCE"] = force
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--config", config, "--verify",
                         "--no-extras"], capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0 and out["scaling"] == "strong"
     assert out["verified"] == {"rows_checked": 2000, "ranks_seen": 1}
-    assert "RCCL" in out["config"]["parallelism"]
+    got = out["config"]["collectives_issued"]
+    if issued is None:
+        assert got["allgather"] == got["padded_allgather"] == got["broadcast_groups"] == 0
+        assert "no collective" in out["config"]["parallelism"]
+    else:
+        assert got[issued] >= 4 and sum(got[k] for k in ("allgather", "padded_allgather", "broadcast_groups")) == got[issued]
+        assert "RCCL" in out["config"]["parallelism"]
 
 
-def test_rccl_exchange_of_unequal_shards_in_process(gpu):
-    """pct_comm_* on one rank inside this process: communicator, all-gather (the equal-size and the per-rank-broadcast
-    form), device-side wait, reductions; the sharded driver gives what the plain handle gives."""
+def test_rccl_exchange_of_unequal_shards_in_process(gpu, monkeypatch):
+    """pct_comm_* on one rank inside this process: communicator, every form of the exchange (ncclAllGather in place,
+    padded ncclAllGather + compaction, group of per-rank ncclBroadcast -- with one rank the shards are trivially equal,
+    so PCT_COMM_FORCE picks the form), the one-exchange-in-flight guard, device-side wait, reductions; the sharded
+    driver gives what the plain handle gives, with and without a forced collective."""
     capi = gpu["capi"]
     from point_cloud_toolbox_amd.dist import RcclExchange, ShardedCurvature
     pts = gpu["shapes"].torus_random(30_001, seed=12)
@@ -949,21 +964,41 @@ def test_rccl_exchange_of_unequal_shards_in_process(gpu):
     ex.barrier()
     send, recv = h.device_alloc(pts.nbytes), h.device_alloc(pts.nbytes)
     h.device_upload(send, pts)
-    ex.end(ex.begin(send, recv, [pts.size]))
-    h.comm_synchronize()
-    back = np.empty_like(pts)
-    h.device_download(recv, back)
-    assert np.array_equal(back, pts)
+    for force, name in (("", "allgather"), ("allgather", "allgather"), ("padded", "padded_allgather"), ("bcast", "broadcast_groups")):
+        if force:
+            monkeypatch.setenv("PCT_COMM_FORCE", force)
+        else:
+            monkeypatch.delenv("PCT_COMM_FORCE", raising=False)
+        before = h.comm_counters()
+        h.device_upload(recv, np.zeros_like(pts))
+        ticket = ex.begin(send, recv, [pts.size])
+        with pytest.raises(ValueError, match="in flight"):
+            ex.begin(send, recv, [pts.size])              # one completion event per handle: refused, not silently wrong
+        ex.end(ticket)
+        h.comm_synchronize()
+        back = np.empty_like(pts)
+        h.device_download(recv, back)
+        assert np.array_equal(back, pts), force
+        after = h.comm_counters()
+        assert after[name] == before[name] + 1 and sum(after.values()) == sum(before.values()) + 1, (force, before, after)
     h.device_free(send)
     h.device_free(recv)
-    sc = ShardedCurvature(len(pts), 30, 0, 1, handle=h, exchange=ex)
-    K, H = sc.step(pts)
-    sc.close()
     ref = capi.Handle(0)
     ref.set_points(pts)
     ref.curvature(30)
     _, K0, H0, _ = ref.get_fit(0, len(pts), coefs=False, H2=False)
-    assert np.array_equal(K, K0) and np.array_equal(H, H0)
+    for force in ("", "padded", "bcast"):
+        if force:
+            monkeypatch.setenv("PCT_COMM_FORCE", force)
+        else:
+            monkeypatch.delenv("PCT_COMM_FORCE", raising=False)
+        sc = ShardedCurvature(len(pts), 30, 0, 1, handle=h, exchange=ex)
+        assert sc.collective == bool(force)
+        K, H = sc.step(pts)
+        K2, H2 = sc.step(pts)                             # the second gather buffer
+        sc.close()
+        assert np.array_equal(K, K0) and np.array_equal(H, H0) and np.array_equal(K2, K0) and np.array_equal(H2, H0), force
+    monkeypatch.delenv("PCT_COMM_FORCE", raising=False)
     with pytest.raises(ValueError):
         h.comm_init(0, 1, b"x" * 128)                    # one communicator per handle
     ex.close()
