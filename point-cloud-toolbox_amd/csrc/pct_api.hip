@@ -266,11 +266,18 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     ctx->levels_fitted = false;
     ctx->skip_dist_req = fuse_fit;
     if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
-    if (k < 1 || k > 127) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,127]", k);
+    if (k < 1 || k > PCT_K_MAX) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,%d]", k, PCT_K_MAX);
     if ((int64_t)k + 1 > ctx->n) return pct_fail(ctx, PCT_ERR_K_TOO_LARGE, "k+1=%d exceeds the cloud size %lld", k + 1, (long long)ctx->n);
     if (!(eps >= 0) || isinf(eps)) eps = 0;
-    const bool auto_req = algo == PCT_KNN_AUTO;
+    bool auto_req = algo == PCT_KNN_AUTO;
     if (algo == PCT_KNN_AUTO) algo = ctx->n >= 4096 ? PCT_KNN_GRID : PCT_KNN_BRUTE;
+    // cKDTree.query takes any k (pct:83).  The fast sweeps sort lists of one or two registers per lane (k <= 127);
+    // longer rows go through the wave-per-query sweeps, whose running list is 64 R wide for any power of two R: the
+    // exact sweep over the cell list (any cloud size), the exhaustive sweep where that was asked for.
+    if (k > 127) {
+        if (algo != PCT_KNN_BRUTE) algo = PCT_KNN_GRID_EXACT;
+        auto_req = false;
+    }
     if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS && algo != PCT_KNN_TREE)
         return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
     ctx->knn_valid = ctx->fit_valid = false;

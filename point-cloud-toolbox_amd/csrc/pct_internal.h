@@ -10,6 +10,7 @@
 #include "../../include/pct_hip.h"
 
 #define PCT_WAVE 64
+#define PCT_K_MAX 511           // longest neighbour row: k + 1 <= 512 = 64 lanes x 8 list registers (wave-per-query sweeps, pct_knn_wide.hip)
 
 // Every kernel launch of the library leaves its source position and kernel name here; the abort hook
 // (pct_api.hip: install_abort_trace) prints it, so that the log of a GPU memory fault -- ROCr aborts the process from
@@ -203,6 +204,7 @@ inline double pct_default_factor(int k) {
         return per_cell / (k + 1);
     }
     const double n = k + 1;                           // R = 2 (768 slots): 0.52 up to k ~ 84, 0.45 at 100, 0.40 at 127
+    if (n > 128) return 0.35;                         // wave-per-query exact sweep only: ~3 (k+1) candidates in the 27 cells of a surface
     return n <= 85 ? 0.52 : n <= 101 ? 0.52 - 0.07 * (n - 85) / 16.0 : 0.45 - 0.05 * (n - 101) / 27.0;
 }
 int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes);

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import atexit
 import threading
+import zlib
 
 import numpy as np
 
@@ -96,6 +97,9 @@ class PointCloud:
         self._device = device
         self._handle = None
         self._cloud_on_device = False
+        self._table_on_device = False   # the neighbour table of the last planting is resident (and not yet replaced)
+        self._uploaded_fp = None        # fingerprint of the points array the device cloud was uploaded from
+        self._n_dev = 0                 # rows of the device cloud
         self._nbr_cache = None
         self._user_neighbors = None
         self._fit_on_device = False
@@ -136,18 +140,37 @@ class PointCloud:
         self.z_domain = [np.min(self.points[:, 2]), np.max(self.points[:, 2])]
 
     # ---------------------------------------------------------------- device
-    def _ctx(self):
+    def _fingerprint(self):
+        """Cheap identity of ``self.points`` as it is NOW: the object, its buffer and layout, and a checksum of about a
+        thousand rows spread over the array.  Assigning ``pc.points`` or rewriting the array in place changes it (an
+        in-place edit of a few rows between the sample can escape; plant_kdtree does not rely on it)."""
+        p = self.points
+        a = np.asarray(p)
+        step = max(1, len(a) // 1024)
+        sample = np.ascontiguousarray(a[::step]) if a.ndim == 2 else a
+        return (id(p), a.shape, a.dtype.str, a.__array_interface__["data"][0], a.strides, zlib.crc32(sample.tobytes()))
+
+    def _upload(self):
+        """The cloud as ``self.points`` holds it now -> device (the reference builds its tree from the array of the
+        moment, pct:74, and gathers from the array of the moment, pct:640)."""
         if self._handle is None:
             self._handle = _capi.Handle(self._device)      # raises without library / GPU
             self._handle.set_stats(self.collect_stats)
-        if not self._cloud_on_device:
-            pts = np.asarray(self.points)
-            if pts.ndim != 2 or pts.shape[1] != 3:
-                raise ValueError("points must have shape (N, 3)")
-            if pts.dtype != np.float64:
-                pts = pts.astype(np.float32, copy=False)
-            self._handle.set_points(pts)
-            self._cloud_on_device = True
+        pts = np.asarray(self.points)
+        if pts.ndim != 2 or pts.shape[1] != 3:
+            raise ValueError("points must have shape (N, 3)")
+        if pts.dtype != np.float64:
+            pts = pts.astype(np.float32, copy=False)
+        self._handle.set_points(pts)
+        self._table_on_device = False                      # a new cloud drops the device table
+        self._cloud_on_device = True
+        self._uploaded_fp = self._fingerprint()
+        self._n_dev = len(pts)
+        return self._handle
+
+    def _ctx(self):
+        if self._handle is None or not self._cloud_on_device:
+            self._upload()
         return self._handle
 
     def close(self):
@@ -159,6 +182,7 @@ class PointCloud:
                 self._user_coefs = self.quadratic_coefficients
             self._handle.close()
             self._handle = None
+            self._table_on_device = False
             self._cloud_on_device = False
             self._fit_on_device = False
             self._device_curv = None
@@ -174,12 +198,15 @@ class PointCloud:
         self.k_neighbors = k_neighbors                      # pct:71
         self.eps = eps
         algo = _ALGORITHMS[algorithm]
-        h = self._ctx()
-        if self._fit_on_device and self._user_coefs is None:
+        if self._fit_on_device and self._user_coefs is None and self._handle is not None:
             # the reference keeps the fitted coefficients across a re-planting (utils.py:495-501):
             # bring them to the host before the device results are invalidated
             self._user_coefs = self.quadratic_coefficients
+        # pct:74 builds a NEW tree from self.points as they are at every planting: so does this (12 B/point over PCIe;
+        # a cloud that was assigned or edited since the last call must not be answered from the old upload)
+        h = self._upload()
         h.knn(k_neighbors, eps or 0.0, algo)
+        self._table_on_device = True
         self.kdtree = _DeviceTree(self)                     # pct:74-75: the tree object later methods query
         self._nbr_cache = None
         self._user_neighbors = None
@@ -189,9 +216,9 @@ class PointCloud:
 
     def _download_neighbors(self):
         if self._nbr_cache is None:
-            if self._handle is None or not hasattr(self._handle, "k"):
+            if self._handle is None or not self._table_on_device:
                 raise AttributeError("'PointCloud' object has no attribute 'neighbor_indices'")
-            idx, dist, cnt = self._handle.get_neighbors(0, self.num_points, True, True, True)
+            idx, dist, cnt = self._handle.get_neighbors(0, self._n_dev, True, True, True)
             self._nbr_cache = (idx, dist, cnt)
         return self._nbr_cache
 
@@ -219,6 +246,15 @@ class PointCloud:
     def fit_explicit_quadratic_surfaces_to_neighborhoods(self):
         """Plane-align + quadric fit of every neighbourhood (pct:635-647)."""
         h = self._ctx()
+        if self._fingerprint() != self._uploaded_fp:
+            # self.points were assigned or rewritten after the upload: pct:640 gathers the CURRENT coordinates with the
+            # table of the last planting -- the table comes to the host (indices, distances, counts: the reference keeps
+            # them as attributes) before the new upload drops it, and goes back as rows for the new cloud
+            if self._table_on_device:
+                self._download_neighbors()
+                if self._user_neighbors is None:
+                    self._user_neighbors = self._nbr_cache[0]
+            h = self._upload()
         if self._user_neighbors is not None:
             h.fit_indices(self._user_neighbors)
         else:
@@ -240,7 +276,7 @@ class PointCloud:
         if not self._fit_on_device:
             raise AttributeError("'PointCloud' object has no attribute 'quadratic_coefficients'")
         if self._coefs_cache is None:
-            self._coefs_cache = self._handle.get_fit(0, self.num_points, K=False, H=False, H2=False)[0]
+            self._coefs_cache = self._handle.get_fit(0, self._n_dev, K=False, H=False, H2=False)[0]
         return self._coefs_cache
 
     @quadratic_coefficients.setter
@@ -252,7 +288,7 @@ class PointCloud:
         """K, H, H^2 from the fitted coefficients (pct:657-674)."""
         if self._user_coefs is None and self._fit_on_device and self._handle is not None:
             if self._device_curv is None:                    # produced by the fused kernel, still on the device
-                self._device_curv = self._handle.get_fit(0, self.num_points, coefs=False)[1:]
+                self._device_curv = self._handle.get_fit(0, self._n_dev, coefs=False)[1:]
             K, H, H2 = self._device_curv
         else:                                                # coefficients the caller supplied, or a re-planted table
             K, H, H2 = self._ctx().curvatures_from_coefficients(np.asarray(self.quadratic_coefficients))
@@ -288,7 +324,7 @@ class PointCloud:
             return 0                                                                   # pct:797-798
         need = upper_bound + 1
         h = self._ctx()
-        own = getattr(h, "k", 0) >= need and not self.eps and self._user_neighbors is None
+        own = self._table_on_device and getattr(h, "k", 0) >= need and not self.eps and self._user_neighbors is None
         if not own:      # keep the planted table untouched: a second context does the k=need sweep
             h = _capi.Handle(self._device)
             pts = np.asarray(self.points)
@@ -316,11 +352,12 @@ class PointCloud:
         self.k_neighbors = k_neighbors
         self.eps = eps
         algo = _ALGORITHMS[algorithm]
-        h = self._ctx()
+        h = self._upload()                                 # the cloud of the moment, as plant_kdtree (pct:74)
         h.curvature(k_neighbors, eps or 0.0, algo)
+        self._table_on_device = True
         self._nbr_cache = None
         self._user_neighbors = None
-        _, K, H, H2 = h.get_fit(0, self.num_points, coefs=False)
+        _, K, H, H2 = h.get_fit(0, self._n_dev, coefs=False)
         self.K_quadratic, self.H_quadratic, self.K_H_sq_quadratic = K, H, H2
         self._plant_token += 1
         self._fit_token = self._plant_token
@@ -387,6 +424,12 @@ def _close_static_handle():
 
 
 def _reference_small_case(pts):
-    # a single point or a malformed block: np.cov of pct:277 has nothing to average -- NaN normal -> the reference's
-    # second finite check fires
-    raise ValueError("Non-finite values after rotation")
+    """What pct:277-280 does with a block the device path does not take (measured with NumPy 2.2): one point or none --
+    np.cov has nothing to average, the covariance is NaN and np.linalg.svd raises LinAlgError("SVD did not converge");
+    a 1-D array -- np.cov returns a scalar and svd refuses it; (m, c != 3) -- svd works but the rotation of pct:315
+    cannot be formed (ValueError from the matrix product)."""
+    if pts.ndim == 1:
+        raise np.linalg.LinAlgError("0-dimensional array given. Array must be at least two-dimensional")
+    if pts.ndim == 2 and pts.shape[1] == 3:
+        raise np.linalg.LinAlgError("SVD did not converge")
+    raise ValueError("Input points must have shape (N, 3)")

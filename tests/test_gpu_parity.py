@@ -265,15 +265,69 @@ def test_scan_line_clouds_against_the_reference(gpu, golden, tag):
 
 
 # ------------------------------------------------------- seeded vs the oracle
-@pytest.mark.parametrize("k", [6, 30, 50, 63, 64, 80, 100, 127])
+@pytest.mark.parametrize("k", [6, 30, 50, 63, 64, 80, 100, 127, 128, 200, 300, 511])
 def test_knn_k_sweep(gpu, k):
-    pts = gpu["shapes"].torus_random(20_000, seed=100 + k)
+    """cKDTree.query takes any k (pct:83): one or two list registers in the fast sweeps up to 127, beyond that the
+    wave-per-query exact sweep with a 256- or 512-wide list (pct_knn_wide.hip)."""
+    pts = gpu["shapes"].torus_random(20_000 if k <= 127 else 6_000, seed=100 + k)
     pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
     pc.plant_kdtree(k, algorithm="grid")
     idx, d = oracle.knn(pts, k)
     assert np.array_equal(pc.neighbor_indices, idx) and np.array_equal(pc.dists, d)
     assert (np.diff(pc.dists, axis=1) >= 0).all()
     assert (pc.neighbor_indices != np.arange(len(pts))[:, None]).all()      # self dropped (pct:84-85)
+
+
+def test_long_rows_fit_and_small_clouds(gpu):
+    """k > 127 through the whole class (fit of 200-neighbour rows), through the exhaustive sweep of a small cloud, and
+    the limits: k = 512 is refused with a message, k + 1 > N as the reference's IndexError path (PCT_ERR_K_TOO_LARGE)."""
+    pts = gpu["shapes"].torus_random(5_000, seed=77)
+    pc = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    pc.plant_kdtree(200)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    ref = oracle.pipeline_batched(pts, 200)
+    assert np.array_equal(pc.neighbor_indices, ref["idx"]) and np.array_equal(pc.dists, ref["dists"])
+    assert oracle.curvature_tolerance_ok(K, ref["K"], 1e-2 * np.abs(ref["K"]).max()).all()
+    assert oracle.curvature_tolerance_ok(H, ref["H"], 1e-2 * np.abs(ref["H"]).max()).all()
+    small = gpu["shapes"].torus_random(700, seed=78)
+    ps = gpu["PointCloud"](points=small, normals=np.zeros((700, 0)))
+    ps.plant_kdtree(300, algorithm="brute")
+    idx, d = oracle.knn(small, 300)
+    assert np.array_equal(ps.neighbor_indices, idx) and np.array_equal(ps.dists, d)
+    with pytest.raises(ValueError, match="outside"):
+        ps.plant_kdtree(512)
+
+
+def test_points_assigned_or_edited_after_a_planting(gpu):
+    """pct:74 builds a new tree from self.points AS THEY ARE at every planting and pct:640 gathers the coordinates of
+    the moment: a cloud that was assigned, or rewritten in place, after an upload must not be answered from the old
+    upload (round 2 did: the device copy was made once)."""
+    shapes = gpu["shapes"]
+    a = shapes.torus_random(6_000, seed=41)
+    b = shapes.egg_carton_random(6_000, seed=42)
+    pc = gpu["PointCloud"](points=a, normals=np.zeros((len(a), 0)))
+    pc.plant_kdtree(30)
+    assert np.array_equal(pc.neighbor_indices, oracle.knn(a, 30)[0])
+    pc.points = b                                         # assigned: the next planting sees the new cloud
+    pc.plant_kdtree(30)
+    rb = oracle.pipeline_batched(b, 30)
+    assert np.array_equal(pc.neighbor_indices, rb["idx"]) and np.array_equal(pc.dists, rb["dists"])
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    assert oracle.curvature_tolerance_ok(K, rb["K"], 1e-2 * np.abs(rb["K"]).max()).all()
+    b *= np.float32(1.5)                                  # rewritten in place (same object, same buffer)
+    pc.plant_kdtree(30)
+    rc = oracle.pipeline_batched(b, 30)
+    assert np.array_equal(pc.neighbor_indices, rc["idx"]) and np.array_equal(pc.dists, rc["dists"])
+    K, H = pc.compute_curvature_fused(30)
+    assert oracle.curvature_tolerance_ok(K, rc["K"], 1e-2 * np.abs(rc["K"]).max()).all()
+    # edited between planting and fit: the reference fits the NEW coordinates with the table of the last planting
+    pc.plant_kdtree(30)
+    old_idx = pc.neighbor_indices.copy()
+    b += np.float32(0.25) * np.sin(7 * b[:, ::-1])        # not a similarity: the table of the old cloud is not the new one's
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    coefs, Kr, Hr, _ = oracle.curvature_batched(b, old_idx, np.arange(len(b)), None)
+    assert np.array_equal(pc.neighbor_indices, old_idx)
+    assert oracle.curvature_tolerance_ok(K, Kr, 1e-2 * np.abs(Kr).max()).all() and oracle.curvature_tolerance_ok(H, Hr, 1e-2 * np.abs(Hr).max()).all()
 
 
 def test_brute_and_grid_agree_bitwise(gpu):
@@ -1331,7 +1385,7 @@ def test_edge_calls(gpu):
     pts = gpu["shapes"].torus_random(5000, seed=3)
     h = capi.Handle(0)
     h.set_points(pts)
-    for bad_k in (0, 128):
+    for bad_k in (0, 512):                                         # (rows of up to 511 neighbours are served, pct_knn_wide.hip)
         with pytest.raises(ValueError):
             h.knn(bad_k)
     h.knn(10, eps=-1.0)                                            # a non-positive eps means "no bound"

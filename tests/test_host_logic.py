@@ -109,3 +109,25 @@ def test_staticmethods_validate_before_touching_the_device(built):
         PC.fit_quadratic_surface(np.zeros(3))
     with pytest.raises(ValueError, match="Input contains non-finite values."):
         PC.fit_quadratic_surface(np.array([[0.0, 0, 0], [1, np.nan, 0], [0, 1, 0]]))
+
+
+def test_plane_rotation_of_malformed_blocks_raises_what_numpy_raises():
+    """pct:277-280 on a block the device path does not take: np.cov of one point (or none) is NaN and np.linalg.svd
+    raises LinAlgError("SVD did not converge"); a 1-D array makes np.cov a scalar, which svd refuses.  (Checked against
+    NumPy 2.2 itself below: the messages are NumPy's.)  No device is touched on these paths."""
+    import numpy as np
+    import warnings
+    from pointCloudToolbox import PointCloud
+    for block in (np.ones((1, 3)), np.zeros((0, 3)), np.ones(3)):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            try:
+                np.linalg.svd(np.cov(block, rowvar=False))
+                raise AssertionError("numpy accepted the block")
+            except np.linalg.LinAlgError as e:
+                want = str(e)
+        try:
+            PointCloud.get_best_fit_plane_and_rotate(block)
+            raise AssertionError("no error")
+        except np.linalg.LinAlgError as e:
+            assert str(e) == want, (block.shape, str(e), want)

@@ -29,21 +29,45 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
             if rng.random() < 0.2: pts = pts.astype(np.float64)
             pc = PointCloud(points=pts, normals=np.zeros((n, 0)))
             refs = {}
+            stale = None                     # the cloud the table in force was planted on, once self.points moved on
             planted = fitted = None          # planted: k of the table in force; fitted: k the coefficients came from
             curv = False
             log = ["new"]
         def ref(k):
             if k not in refs:
-                refs.clear(); refs[k] = oracle.pipeline_batched(pts, k)
+                refs.clear()
+                if stale is None:
+                    refs[k] = oracle.pipeline_batched(pts, k)
+                else:                        # table of the old cloud, coordinates of the new one
+                    idx, dists = oracle.knn(stale, k)
+                    coefs, K, H, H2 = oracle.curvature_batched(pts, idx, np.arange(n), None)
+                    refs[k] = dict(idx=idx, dists=dists, coefs=coefs, K=K, H=H, H2=H2)
             return refs[k]
-        ops = ["plant", "plant"]
-        if planted: ops += ["idx", "dists", "fit", "compute", "set_idx", "tree", "close"]
+        ops = ["plant", "plant", "assign_points", "edit_points"]
+        if planted: ops += ["idx", "dists", "fit", "compute", "set_idx", "close"] + (["tree"] if stale is None else [])
+        # (after the cloud has changed, the reference's table of the last planting is still an attribute and a fit
+        # gathers the NEW coordinates with it, pct:640: table_of = the cloud the table in force was planted on)
         if fitted: ops += ["coefs", "curv", "set_coefs"]
         if curv: ops += ["read_curv"]
         op = str(rng.choice(ops)); it += 1; log.append(op)
         if verbose: print(it, op, planted, fitted, flush=True)
         bad = None
-        if op == "plant":
+        if op in ("assign_points", "edit_points"):
+            # pct:74 / pct:640 read self.points as they are at the call: a new array assigned, or the array rewritten in
+            # place, must be what the next planting and the next fit see
+            if planted and stale is None: stale = pts
+            if op == "assign_points":
+                pts = (pts * np.float32(1.0 + 0.01 * rng.random()) + np.float32(0.001)).astype(pts.dtype)
+                pc.points = pts
+            else:
+                pts = pts.copy() if stale is pts else pts
+                if pc.points is not pts: pc.points = pts
+                pts *= pts.dtype.type(1.0 + 0.01 * rng.random())       # in place
+            refs.clear()
+            fitted = None; curv = False      # (what was fitted before belongs to a cloud this tool no longer holds)
+        elif op == "plant":
+            if stale is not None: fitted = None; curv = False      # (a fit made with the old table on the new cloud: this tool's reference for it goes with the table)
+            stale = None; refs.clear()
             k = min(int(rng.choice([10, 15, 30, 50, 70])), n - 1)     # (k = 6 is an exactly determined fit: its agreement with
                                                                        # the oracle's SVD solve is a matter of conditioning, not of state)
             pc.plant_kdtree(k, algorithm=str(rng.choice(["auto", "grid", "brute", "tree"])))
