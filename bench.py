@@ -50,6 +50,58 @@ def measured_traffic(n_points, k):
     return None, None
 
 
+def measured_instructions():
+    """Wave-instructions per launch from the newest committed SQ counter passes (STATIC, like `traffic`): what the
+    issue-bound view of the kernels is computed from.  {kernel: {"valu": n, "salu": n, "lds": n}}, file name."""
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_sq_counters.json")), reverse=True):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            out = {}
+            for name, c in d.items():
+                out[name] = {"valu": c.get("SQ_INSTS_VALU"), "salu": c.get("SQ_INSTS_SALU"), "lds": c.get("SQ_INSTS_LDS")}
+            return out, "profiles/" + os.path.basename(path)
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
+def class_surface(local, k):
+    """What a drop-in user of the reference's class gets (utils.py:481-501's call sequence without the meshing):
+    PointCloud(points=...) -> plant_kdtree(k) -> compute_pointwise_explicit_quadratic_curvature() -> K, H as NumPy.
+    A fresh object in the warm process; wall time per call."""
+    from pointCloudToolbox import PointCloud
+    n = len(local)
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        pc = PointCloud(points=local, normals=np.zeros((n, 0)))
+        t1 = time.perf_counter()
+        pc.plant_kdtree(k, algorithm="grid")
+        t2 = time.perf_counter()
+        K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+        t3 = time.perf_counter()
+        pc.close()
+        r = {"constructor_ms": 1e3 * (t1 - t0), "plant_kdtree_ms": 1e3 * (t2 - t1), "curvature_ms": 1e3 * (t3 - t2),
+             "total_ms": 1e3 * (t3 - t0)}
+        if best is None or r["plant_kdtree_ms"] + r["curvature_ms"] < best["plant_kdtree_ms"] + best["curvature_ms"]:
+            best = r
+    # the fused extension of the class: one call, the neighbour table never leaves the device
+    pc = PointCloud(points=local, normals=np.zeros((n, 0)))
+    pc.compute_curvature_fused(k, algorithm="grid")
+    t0 = time.perf_counter()
+    pc.compute_curvature_fused(k, algorithm="grid")
+    fused_ms = 1e3 * (time.perf_counter() - t0)
+    pc.close()
+    best.update({"value": n / (best["total_ms"] - best["constructor_ms"]) * 1e3, "unit": "points/s",
+                 "what": "PointCloud(points=...) [the constructor's three matrix norms, pct:45-47, are host work and listed apart] -> "
+                         "plant_kdtree(k) [upload 12 B/point, cell list, sweep writing indices AND distances] -> "
+                         "compute_pointwise_explicit_quadratic_curvature() [fit + K, H to the host]; fresh object, warm process, best of 3; "
+                         "value = points / (plant + curvature)",
+                 "compute_curvature_fused_ms": fused_ms})
+    return best
+
+
 def cpu_baseline(pts, k, seconds_target=15.0):
     """1-core reference-faithful port (oracle loop) on a bounded sample of the same cloud."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -343,16 +395,26 @@ def main():
             extras["fit_svd_rows"] = handle.timings()["fit_svd_rows"]
             handle.set_stats(False)
             # end to end: host coordinates in (12 B/point over PCIe), K and H out (8 B/point), every step
-            m = max(3, args.steps // 4)
-            handle.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(m):
+            m = max(10, args.steps // 2)
+            t0 = 0.0
+            for it in range(m + 1):                           # (round 0 warms the host pages of the output block)
+                if it == 1:
+                    handle.synchronize()
+                    t0 = time.perf_counter()
                 handle.set_points(local)
                 handle.curvature(k, eps, _capi.KNN_GRID)
                 handle.get_fit(0, n_total, coefs=False, H2=False)
             e2e = (time.perf_counter() - t0) / m
             extras["end_to_end"] = {"value": n_total / e2e, "unit": "points/s", "ms_per_step": 1e3 * e2e,
-                                    "what": "H2D of float32 coordinates (12 B/point, pageable host memory) + step + D2H of K, H (8 B/point)"}
+                                    "what": "H2D of float32 coordinates (12 B/point, pageable host memory) + step + D2H of K, H (8 B/point, one copy)"}
+            # the sweep in the mode SURVEY 8(d) prices: plant_kdtree's, which writes indices AND distances (12 + 8k B/point)
+            acc8 = 0.0
+            for _ in range(10):
+                handle.knn(k, eps, _capi.KNN_GRID)
+                acc8 += handle.timings()["knn_fast_ms"]
+            extras["_knn_fast_ms_with_distances"] = acc8 / 10
+            handle.curvature(k, eps, _capi.KNN_GRID)
+            extras["class_surface"] = class_surface(local, k)
             # a fresh handle in the warm process: every buffer allocated again, cell size searched from scratch
             t0 = time.perf_counter()
             h1 = _capi.Handle(local_rank)
@@ -369,8 +431,11 @@ def main():
         steps = args.steps
         nq = hi - lo
         fast_ms = acc["knn_fast_ms"]
-        knn_avg_s = fast_ms / steps / 1e3                     # the dominant kernel (k_knn_fast) alone
-        algo_bytes = nq * (12 + 8 * k)                        # B_knn(k) = 12 + 8k per point
+        knn_avg_s = fast_ms / steps / 1e3                     # the dominant kernel alone (hipEvents on the handle's stream)
+        # The timed step is the FUSED call: its sweep writes the index table only (12 + 4k B/point) -- the fit never
+        # reads distances, pct_get_neighbors derives them on demand.  SURVEY 8d's B_knn(k) = 12 + 8k prices the sweep
+        # that writes both (plant_kdtree's): measured next to it when the extras run (roofline.with_distances).
+        algo_bytes = nq * (12 + 4 * k)
         achieved = algo_bytes / knn_avg_s / 1e9
         traffic, traffic_source = measured_traffic(nq, k)
         par = f"point-index-range shards x{world}"
@@ -405,15 +470,49 @@ def main():
                                    f"({cfg['base']})",
                        "points_total": n_total, "k": k, "parallelism": par,
                        **({"collectives_issued": issued} if issued is not None else {})},
-            "roofline": {"bound": "hbm", "kernel": "k_knn_fast", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": fast_ms / steps},
+            "roofline": {"bound": "hbm", "kernel": "k_knn_pair, no distance table (the fused step's sweep)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+                         "algorithmic_bytes_per_launch": algo_bytes, "algorithmic_bytes_per_point": "12 + 4k (coordinates in, index table out)",
+                         "avg_launch_ms": fast_ms / steps},
             "stage_ms": {"grid_build": acc["grid_ms"] / steps, "knn": acc["knn_ms"] / steps, "knn_fast_kernel": fast_ms / steps,
                          "fit_curvature": acc["fit_ms"] / steps},
             "repeat_ms_per_step": repeats,
             "grid_points_per_rank": last_tm["grid_points"],
             "target_points_per_s": 1e7,
         }
+        w8 = extras.pop("_knn_fast_ms_with_distances", None)
+        if w8:
+            b8 = nq * (12 + 8 * k)
+            out["roofline"]["with_distances"] = {
+                "what": "the same kernel in plant_kdtree's mode (indices AND float32 distances written): SURVEY 8d's B_knn(k) = 12 + 8k",
+                "algorithmic_bytes_per_launch": b8, "avg_launch_ms": w8, "achieved": b8 / w8 / 1e6, "unit": "GB/s",
+                "frac": b8 / w8 / 1e6 / HBM_PEAK_GBPS}
+        # every kernel of the step against the resource that binds it (none is HBM-bound: DESIGN 4).  Issue view: a
+        # vector instruction other than plain float32 arithmetic occupies a SIMD for 4 cycles on this part
+        # (tools/ubench/valu_rate.hip: v_med3, DPP moves, v_cmp, integer, every fp64 op; v_fma_f32 2.5), 1024 SIMDs,
+        # 2.4 GHz peak clock; instruction counts are STATIC figures from the committed SQ counter passes.
+        if args.config == "c3" and nq == 1_000_000 and k == 50 and not dist_mode:
+            insts, insts_src = measured_instructions()
+            simd_cycles = 1024 * 2.4e9
+            rk = {}
+
+            def issue(kernel, ms):
+                v = (insts.get(kernel) or {}).get("valu")
+                return {} if not v or not ms else {"valu_insts_per_launch": v, "frac_of_valu_issue_peak": v * 4.0 / (ms * 1e-3 * simd_cycles)}
+            rk["k_knn_pair"] = {"bound": "valu issue", **issue("k_knn_pair", fast_ms / steps), "avg_launch_ms": fast_ms / steps,
+                                "hbm_frac": achieved / HBM_PEAK_GBPS}
+            fit_ms_ = acc["fit_ms"] / steps
+            fit_bytes = nq * (16 * k + 48)                             # B_fit(k) = 16k + 48
+            rk["k_fit"] = {"bound": "valu issue (fp64)", **issue("k_fit", fit_ms_), "avg_launch_ms": fit_ms_,
+                           "algorithmic_bytes_per_launch": fit_bytes, "hbm_achieved_GBps": fit_bytes / fit_ms_ / 1e6,
+                           "hbm_frac": fit_bytes / fit_ms_ / 1e6 / HBM_PEAK_GBPS}
+            grid_ms_ = acc["grid_ms"] / steps
+            grid_bytes = nq * 76
+            rk["cell_list_build"] = {"bound": "launch chain + one host synchronisation", "avg_ms": grid_ms_,
+                                     "algorithmic_bytes": grid_bytes, "hbm_achieved_GBps": grid_bytes / grid_ms_ / 1e6,
+                                     "hbm_frac": grid_bytes / grid_ms_ / 1e6 / HBM_PEAK_GBPS}
+            rk["instruction_counts_source"] = insts_src
+            out["roofline_kernels"] = rk
         out.update(extras)
         if verified is not None:
             out["verified"] = verified

@@ -213,6 +213,11 @@ int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out);
  * '#' comments and blank lines skipped.  Values are correctly rounded float64 (what Python's float() gives). */
 int pct_text_shape(const char* path, int64_t* rows, int32_t* cols);
 int pct_text_load(const char* path, int64_t rows, int32_t cols, double* out);
+/* The constructor's three matrix norms (pct:45-47) from one multi-threaded pass over the (N, 3) array: out10 =
+ * {sum|x|, sum|y|, sum|z| (float64), largest row sum (|x| + |y|) + |z| in the array's dtype, Gram matrix xx xy xz yy yz
+ * zz (float64)}; the spectral norm is the square root of the Gram matrix' largest eigenvalue.  NaN input: NaN out. */
+int pct_matrix_norms_f32(const float* xyz, int64_t n, double* out10);
+int pct_matrix_norms_f64(const double* xyz, int64_t n, double* out10);
 /* repr(float(x)) as Python prints it -- what an f-string gives for a np.float32 widened to double -- into out32
  * (>= 32 bytes, not NUL-terminated); returns the length. */
 int pct_format_float(double x, char* out32);

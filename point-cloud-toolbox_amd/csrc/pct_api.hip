@@ -645,9 +645,15 @@ int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end, float* coefs, float* K
         d_s = (float*)ctx->stage_b.p;
         PCT_TRY(pct_launch_gather_fit(ctx, off, rows, d_c, K ? d_s : nullptr, H ? d_s + rows : nullptr, H2 ? d_s + 2 * rows : nullptr));
         if (coefs) PCT_HIP(ctx, hipMemcpyAsync(coefs, d_c, (size_t)rows * 6 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (K) PCT_HIP(ctx, hipMemcpyAsync(K, d_s, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (H) PCT_HIP(ctx, hipMemcpyAsync(H, d_s + rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (H2) PCT_HIP(ctx, hipMemcpyAsync(H2, d_s + 2 * rows, (size_t)rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        // the three arrays lie back to back on the device; where the caller's do too, one copy moves the run
+        float* host[3] = {K, H, H2};
+        for (int i = 0; i < 3;) {
+            if (!host[i]) { ++i; continue; }
+            int j = i + 1;
+            while (j < 3 && host[j] == host[j - 1] + rows) ++j;
+            PCT_HIP(ctx, hipMemcpyAsync(host[i], d_s + (size_t)i * rows, (size_t)(j - i) * rows * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            i = j;
+        }
         PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
         return PCT_OK;
     }

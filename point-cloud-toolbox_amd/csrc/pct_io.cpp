@@ -14,6 +14,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <limits>
 #include <vector>
 
 #include <fcntl.h>
@@ -296,3 +297,64 @@ int pct_write_ply_ascii(const char* path, const float* xyz, const float* gaussia
 }
 
 }  // extern "C"
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The three matrix norms of the constructor (pct:45-47: np.linalg.norm(points, 1 | 2 | inf); nothing reads them, but
+// a drop-in constructor computes them): ONE multi-threaded pass over the (N, 3) array instead of numpy's transposed
+// copies -- column sums of |x| in float64, the largest row sum of |x| in the array's own dtype and numpy's order
+// ((|x| + |y|) + |z|), the six entries of the 3 x 3 Gram matrix in float64 (its largest eigenvalue is sigma_1^2).
+// out9 = {sum|x|, sum|y|, sum|z|, max row sum, gxx, gxy, gxz, gyy, gyz, gzz} -> 10 doubles; non-finite input makes
+// the Gram entries non-finite (the caller raises what numpy's SVD raises).
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <class T>
+void norms_range(const T* p, int64_t lo, int64_t hi, double* o) {
+    double s0 = 0, s1 = 0, s2 = 0, g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
+    T row_max = 0;
+    bool nan_row = false;
+    for (int64_t i = lo; i < hi; ++i) {
+        const T x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+        const T ax = x < 0 ? -x : x, ay = y < 0 ? -y : y, az = z < 0 ? -z : z;
+        s0 += (double)ax; s1 += (double)ay; s2 += (double)az;
+        const T r = (ax + ay) + az;
+        if (r > row_max) row_max = r;
+        nan_row |= !(r == r);
+        const double dx = x, dy = y, dz = z;
+        g00 += dx * dx; g01 += dx * dy; g02 += dx * dz; g11 += dy * dy; g12 += dy * dz; g22 += dz * dz;
+    }
+    o[0] = s0; o[1] = s1; o[2] = s2; o[3] = nan_row ? std::numeric_limits<double>::quiet_NaN() : (double)row_max;
+    o[4] = g00; o[5] = g01; o[6] = g02; o[7] = g11; o[8] = g12; o[9] = g22;
+}
+
+template <class T>
+int matrix_norms(const T* p, int64_t n, double* out10) {
+    if (!p || !out10 || n <= 0) return 1;
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads < 1) threads = 1;
+    if (threads > 16) threads = 16;
+    if (n < 200000) threads = 1;
+    std::vector<double> part((size_t)threads * 10, 0.0);
+    std::vector<std::thread> th;
+    const int64_t per = (n + threads - 1) / threads;
+    for (int t = 1; t < threads; ++t)
+        th.emplace_back([&, t] { norms_range(p, std::min<int64_t>(n, t * per), std::min<int64_t>(n, (t + 1) * per), &part[(size_t)t * 10]); });
+    norms_range(p, 0, std::min<int64_t>(n, per), &part[0]);
+    for (auto& x : th) x.join();
+    for (int j = 0; j < 10; ++j) out10[j] = 0;
+    out10[3] = -1;
+    for (int t = 0; t < threads; ++t) {
+        const double* o = &part[(size_t)t * 10];
+        if ((int64_t)t * per >= n) break;
+        for (int j = 0; j < 10; ++j) {
+            if (j == 3) { if (!(o[3] <= out10[3])) out10[3] = o[3] != o[3] ? o[3] : (o[3] > out10[3] ? o[3] : out10[3]); }
+            else out10[j] += o[j];
+        }
+        if (out10[3] != out10[3]) {}
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int pct_matrix_norms_f32(const float* xyz, int64_t n, double* out10) { return matrix_norms(xyz, n, out10); }
+extern "C" int pct_matrix_norms_f64(const double* xyz, int64_t n, double* out10) { return matrix_norms(xyz, n, out10); }
