@@ -3,6 +3,8 @@
 Bars (SURVEY 8c):  neighbour indices / float32 distances bit-exact;
 K, H:  |x - ref| <= 1e-5 * max(|ref|, 1e-2 * scale)  with scale = max|ref| of the input.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -65,6 +67,26 @@ def test_file_constructor_golden(gpu, golden, tmp_path):
     K, H = pc.compute_pointwise_explicit_quadratic_curvature()
     assert np.array_equal(pc.neighbor_indices, g["idx"]) and np.array_equal(pc.dists, g["dists"])
     assert_curvature(K, H, g["K"], g["H"])
+
+
+def test_whole_bunny_scan_through_the_file_constructor(gpu, golden, tmp_path):
+    """BASELINE.md's first plumbing line in full: all 35 947 rows of sample_scans/bunny.txt, file constructor (parser,
+    float32 cast, max-shift of pct:56-57), k = 30, against the unmodified reference run on the whole file
+    (oracle/make_goldens_bunny_full.py: 3 000 sampled rows of every output, the shifted cloud in full)."""
+    g = golden("g4_bunny_full_file_k30_sample.npz")
+    raw = np.load(os.path.join(os.path.dirname(__file__), "golden", "bunny_xyz_f32.npy"))
+    assert len(raw) == int(g["n"]) == 35947
+    f = tmp_path / "bunny.txt"
+    np.savetxt(f, raw.astype(np.float64))                  # (the float32 values of the scan's text, as text again)
+    pc = gpu["PointCloud"](str(f))
+    assert pc.points.dtype == np.float32 and np.array_equal(pc.points, g["points"])     # the shifted cloud, bit for bit
+    pc.plant_kdtree(30)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    rows = g["rows"]
+    assert np.array_equal(pc.neighbor_indices[rows], g["idx"]) and np.array_equal(pc.dists[rows], g["dists"])
+    assert_curvature(K[rows], H[rows], g["K"], g["H"])
+    coefs = np.asarray(pc.quadratic_coefficients)[rows]
+    assert (coefs == g["coefs"]).all(1).mean() > 0.98
 
 
 def test_regular_grid_ties(gpu, golden):
@@ -1368,6 +1390,22 @@ def test_random_cross_check_large_and_tiny(gpu):
     done, bad = _tool("fuzz_tiny").run(seed0=13, budget=30.0, cases=300)
     assert bad is None, bad
     assert done >= 100
+
+
+def test_random_cross_checks_with_exact_size_buffers(gpu, monkeypatch):
+    """The same tools with PCT_NO_HEADROOM=1: every device buffer is allocated at exactly the size asked for and moves on
+    every growing request, so that an over-read past a table or a pointer kept across a reserve cannot hide in
+    pct_reserve's spare bytes (size / 8 + 256) -- which is where the tie-break over-read of round 2 hid for two rounds."""
+    monkeypatch.setenv("PCT_NO_HEADROOM", "1")
+    done, bad = _tool("fuzz_tiny").run(seed0=29, budget=25.0, cases=250)
+    assert bad is None, bad
+    assert done >= 80
+    done, bad = _tool("fuzz_gpu").run(seed0=17, budget=25.0, cases=60, verbose=False)
+    assert bad is None, bad
+    assert done >= 15
+    done, bad = _tool("fuzz_stream").run(seed0=9, budget=20.0, cases=120, verbose=False)
+    assert bad is None, bad
+    assert done >= 30
 
 
 def test_random_stream_of_clouds_through_one_handle(gpu):

@@ -99,3 +99,18 @@ def test_error_conventions():
         oracle.plane_align(bad)
     with pytest.raises(ValueError, match=r"shape \(N, 3\)"):
         oracle.quadric_fit(np.zeros((5, 2)))
+
+
+def test_whole_bunny_scan_pins_the_oracle(golden):
+    """G4-full: the reference on ALL of sample_scans/bunny.txt through its file constructor (k = 30): the loop
+    restatement reproduces 150 of the sampled rows bit for bit, the batched one all 3 000 within the contract."""
+    g = golden("g4_bunny_full_file_k30_sample.npz")
+    pts, rows, k = g["points"], g["rows"], int(g["k"])
+    some = rows[::20]
+    r = oracle.pipeline_loop(pts, k, list(some))
+    for key in ("idx", "dists", "coefs", "K", "H", "H2"):
+        assert np.array_equal(r[key], g[key][::20]), key
+    b = oracle.pipeline_batched(pts, k, rows=rows)
+    assert np.array_equal(b["idx"], g["idx"]) and np.array_equal(b["dists"], g["dists"])
+    fK, fH = 1e-2 * np.abs(g["K"]).max(), 1e-2 * np.abs(g["H"]).max()
+    assert oracle.curvature_tolerance_ok(b["K"], g["K"], fK).all() and oracle.curvature_tolerance_ok(b["H"], g["H"], fH).all()
