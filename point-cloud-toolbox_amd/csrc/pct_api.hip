@@ -72,12 +72,22 @@ int pct_device_count(int* count) {
 // action).  Twice in two rounds a GPU test run died with nothing but "Fatal Python error: Aborted" in its log -- no
 // GPU fault line, no glibc diagnostic: the raiser is some library's bare abort(), possibly on a runtime
 // helper thread that a Python traceback cannot show.  Tests, bench.py and smoke() switch this on.
-extern "C++" { const char* volatile pct_last_launch = "(none)"; }
+extern "C++" { const char* pct_last_launch = "(none)"; }
 static struct sigaction g_prev_abrt;
 static int g_abrt_fd = 2;       // PCT_ABORT_TRACE=<fd>: a descriptor of the REAL stderr (a test runner that captures fd 2
                                 // -- pytest -- would swallow the trace with the dying process; tests/conftest.py dups it
                                 // before capturing starts)
+// Best effort only: backtrace() and backtrace_symbols_fd() are not async-signal-safe (an abort raised from inside
+// malloc or the unwinder can hang here instead of dying) -- the hook is OPT-IN (PCT_ABORT_TRACE: tests, bench.py and
+// smoke() set it; a host application that loads the library does not get its SIGABRT disposition touched).
+static volatile sig_atomic_t g_in_abort_trace = 0;
 static void abort_trace(int) {
+    if (g_in_abort_trace) {                    // a second abort while tracing the first: give up tracing
+        sigaction(SIGABRT, &g_prev_abrt, nullptr);
+        raise(SIGABRT);
+        return;
+    }
+    g_in_abort_trace = 1;
     static const char head[] = "\n[pct] SIGABRT -- native backtrace of the raising thread";
     const int fd = g_abrt_fd;
     (void)!write(fd, head, sizeof(head) - 1);
@@ -90,7 +100,7 @@ static void abort_trace(int) {
     (void)!write(fd, ":\n", 2);
     static const char last[] = "[pct] last kernel launched by the library: ";
     (void)!write(fd, last, sizeof(last) - 1);
-    const char* ll = pct_last_launch;
+    const char* ll = __atomic_load_n(&pct_last_launch, __ATOMIC_RELAXED);
     (void)!write(fd, ll, strlen(ll));
     (void)!write(fd, "\n", 1);
     void* frames[64];
@@ -112,7 +122,7 @@ static void install_abort_trace() {
         memset(&sa, 0, sizeof(sa));
         sa.sa_handler = abort_trace;
         sigemptyset(&sa.sa_mask);
-        sa.sa_flags = SA_NODEFER;
+        sa.sa_flags = 0;
         sigaction(SIGABRT, &sa, &g_prev_abrt);
     });
 }

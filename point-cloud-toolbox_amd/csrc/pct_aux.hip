@@ -186,9 +186,9 @@ int pct_voxel_downsample_device(pct_ctx* ctx, const void* d_xyz, bool f64, int64
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * 3 * sizeof(int)));
     const int blocks = (int)((n + 255) / 256);
     if (f64)
-        hipLaunchKernelGGL(k_voxel_keys<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_xyz, n, voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
+        PCT_LAUNCH(k_voxel_keys<double>, dim3(blocks), dim3(256), 0, ctx->stream, (const double*)d_xyz, n, voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
     else
-        hipLaunchKernelGGL(k_voxel_keys<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)d_xyz, n, (float)voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
+        PCT_LAUNCH(k_voxel_keys<float>, dim3(blocks), dim3(256), 0, ctx->stream, (const float*)d_xyz, n, (float)voxel, (int*)ctx->cell_of.p, (int*)ctx->red.p);
     int mm[8];
     PCT_HIP(ctx, hipMemcpyAsync(mm, ctx->red.p, sizeof(mm), hipMemcpyDeviceToHost, ctx->stream));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -203,13 +203,13 @@ int pct_voxel_downsample_device(pct_ctx* ctx, const void* d_xyz, bool f64, int64
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(blocks + 1) * sizeof(int)));
     PCT_HIP(ctx, hipMemsetAsync(ctx->cell_cnt.p, 0xFF, (size_t)slots * sizeof(unsigned long long), ctx->stream));
     PCT_HIP(ctx, hipMemsetAsync(ctx->cell_own.p, 0x7F, (size_t)slots * sizeof(int), ctx->stream));     // 0x7F7F7F7F > any index
-    hipLaunchKernelGGL(k_voxel_insert, dim3(blocks), dim3(256), 0, ctx->stream, (const int*)ctx->cell_of.p, n, mm[0], mm[1], mm[2],
+    PCT_LAUNCH(k_voxel_insert, dim3(blocks), dim3(256), 0, ctx->stream, (const int*)ctx->cell_of.p, n, mm[0], mm[1], mm[2],
                        (unsigned long long*)ctx->cell_cnt.p, (int*)ctx->cell_own.p, slots - 1);
-    hipLaunchKernelGGL(k_voxel_flag, dim3(blocks), dim3(256), 0, ctx->stream, (const int*)ctx->cell_of.p, n, mm[0], mm[1], mm[2],
+    PCT_LAUNCH(k_voxel_flag, dim3(blocks), dim3(256), 0, ctx->stream, (const int*)ctx->cell_of.p, n, mm[0], mm[1], mm[2],
                        (const unsigned long long*)ctx->cell_cnt.p, (const int*)ctx->cell_own.p, slots - 1,
                        (unsigned char*)ctx->cell_fill.p, (int*)ctx->scan_tmp.p);
-    hipLaunchKernelGGL(k_scan_int, dim3(1), dim3(1024), 0, ctx->stream, (int*)ctx->scan_tmp.p, blocks);
-    hipLaunchKernelGGL(k_voxel_compact, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned char*)ctx->cell_fill.p, n,
+    PCT_LAUNCH(k_scan_int, dim3(1), dim3(1024), 0, ctx->stream, (int*)ctx->scan_tmp.p, blocks);
+    PCT_LAUNCH(k_voxel_compact, dim3(blocks), dim3(256), 0, ctx->stream, (const unsigned char*)ctx->cell_fill.p, n,
                        (const int*)ctx->scan_tmp.p, d_out);
     PCT_HIP(ctx, hipGetLastError());
     int total = 0;
@@ -223,7 +223,7 @@ int pct_voxel_downsample_device(pct_ctx* ctx, const void* d_xyz, bool f64, int64
 int pct_launch_surface_variation(pct_ctx* ctx, float* d_out) {
     const bool sorted = ctx->knn_sorted_space;
     const int64_t rows = ctx->q_end - ctx->q_begin;
-    hipLaunchKernelGGL(k_surface_variation, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, ctx->stream,
+    PCT_LAUNCH(k_surface_variation, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, ctx->stream,
                        (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->owned_pos.p : nullptr,
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->nbr_pitch, ctx->k, rows, ctx->q_begin, d_out);
     PCT_HIP(ctx, hipGetLastError());

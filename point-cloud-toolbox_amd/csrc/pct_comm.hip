@@ -208,7 +208,7 @@ int pct_comm_allgather_f32(pct_ctx* ctx, const void* dev_send, void* dev_recv, c
             PCT_HIP(ctx, hipMemcpyAsync(mine, dev_send, (size_t)counts[c->rank] * sizeof(float), hipMemcpyDeviceToDevice, c->stream));
         PCT_NCCL(ctx, c, c->AllGather(mine, c->padded, (size_t)most, ncclFloat32, c->comm, c->stream));
         const int bx = (int)((most + 255) / 256 < 2048 ? (most + 255) / 256 : 2048);
-        hipLaunchKernelGGL(k_unpad, dim3(bx > 0 ? bx : 1, c->world), dim3(256), 0, c->stream, (const float*)c->padded, most,
+        PCT_LAUNCH(k_unpad, dim3(bx > 0 ? bx : 1, c->world), dim3(256), 0, c->stream, (const float*)c->padded, most,
                            off, c->world, (float*)dev_recv);
         PCT_HIP(ctx, hipGetLastError());
     } else {

@@ -55,6 +55,7 @@ struct FitArgs {
     int* flag_count;
     unsigned n_pts;          // records in pts: a table entry outside [0, n_pts) is never dereferenced (the row reads NaN)
     const int* row_mask;     // MASKED instantiation: only the rows with a non-zero entry are fitted (passes of the density-adaptive sweep)
+    int svd_accumulate;      // the count of rows handed to k_fit_svd is ADDED to the host word (the passes of one fused call)
 };
 
 // Smallest Cholesky pivot ratio d_j / g_jj (= sin^2 of the angle between design column j and the span of the columns
@@ -546,7 +547,7 @@ template <bool F64, bool OUT64>
 __global__ __launch_bounds__(64) void k_fit_svd(FitArgs a, const int* __restrict__ list, const int* __restrict__ list_count,
                                                 long long* __restrict__ host_count) {
     const int total = *list_count;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = total;           // pinned host word: read at the caller's next synchronisation
+    if (blockIdx.x == 0 && threadIdx.x == 0) *host_count = (a.svd_accumulate ? *host_count : 0ll) + total;   // pinned host word: read at the caller's next synchronisation
     const float nanf_ = __int_as_float(0x7fc00000);
     for (int64_t it = (int64_t)blockIdx.x * 64 + threadIdx.x; it < total; it += (int64_t)gridDim.x * 64) {
         const int64_t row = list[it];
@@ -719,9 +720,9 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     a.flag_list = (int*)ctx->fit_flag.p + 16;
 #define PCT_FIT_LAUNCH(F_, O_)                                                                                      \
     do {                                                                                                            \
-        if (a.row_mask && staged && !O_) hipLaunchKernelGGL((k_fit<F_, false, true, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a); \
-        else if (staged) hipLaunchKernelGGL((k_fit<F_, O_, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);  \
-        else hipLaunchKernelGGL((k_fit<F_, O_, false>), dim3(blocks), dim3(kFitBlock), 0, ctx->stream, a);          \
+        if (a.row_mask && staged && !O_) PCT_LAUNCH((k_fit<F_, false, true, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a); \
+        else if (staged) PCT_LAUNCH((k_fit<F_, O_, true>), dim3(blocks), dim3(kFitBlock), lds, ctx->stream, a);  \
+        else PCT_LAUNCH((k_fit<F_, O_, false>), dim3(blocks), dim3(kFitBlock), 0, ctx->stream, a);          \
     } while (0)
     if (a.coefs64) {
         if (f64) PCT_FIT_LAUNCH(true, true);
@@ -735,13 +736,13 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     long long* note = (long long*)(ctx->pin + 2048);
     if (a.coefs64) {
         if (f64)
-            hipLaunchKernelGGL((k_fit_svd<true, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
+            PCT_LAUNCH((k_fit_svd<true, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
         else
-            hipLaunchKernelGGL((k_fit_svd<false, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
+            PCT_LAUNCH((k_fit_svd<false, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     } else if (f64)
-        hipLaunchKernelGGL((k_fit_svd<true, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
+        PCT_LAUNCH((k_fit_svd<true, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     else
-        hipLaunchKernelGGL((k_fit_svd<false, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
+        PCT_LAUNCH((k_fit_svd<false, false>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -776,6 +777,7 @@ int pct_launch_fit_pass(pct_ctx* ctx, int64_t rows) {
     a.H2 = (float*)ctx->H2.p;
     a.n_pts = (unsigned)ctx->n_grid;
     a.row_mask = (const int*)ctx->row_done.p;
+    a.svd_accumulate = 1;                      // (pct_knn_levels zeroes the host word before the first pass)
     return launch(ctx, a, ctx->has_f64);
 }
 
@@ -820,7 +822,7 @@ int pct_launch_fit_table(pct_ctx* ctx) {
 }
 
 int pct_launch_gather_fit(pct_ctx* ctx, int64_t first, int64_t rows, float* d_coefs, float* d_K, float* d_H, float* d_H2) {
-    hipLaunchKernelGGL(k_gather_fit, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->row_of.p,
+    PCT_LAUNCH(k_gather_fit, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const int*)ctx->row_of.p,
                        first, rows, (const float*)ctx->coefs.p, (const float*)ctx->K.p, (const float*)ctx->H.p,
                        (const float*)ctx->H2.p, d_coefs, d_K, d_H, d_H2);
     PCT_HIP(ctx, hipGetLastError());
@@ -879,7 +881,7 @@ int pct_launch_fit_rows_f64(pct_ctx* ctx, const int32_t* d_idx, const int32_t* d
 int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_row, int64_t n_samples, int n_lo, int n_hi, int* d_table,
                            int pitch, int* d_cnt, int64_t* d_row_query) {
     const int64_t rows = n_samples * (n_hi - n_lo + 1);
-    hipLaunchKernelGGL(k_prefix_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_sample_row,
+    PCT_LAUNCH(k_prefix_rows, dim3((unsigned)rows), dim3(256), 0, ctx->stream, d_sample_row,
                        ctx->knn_sorted_space ? (const int*)ctx->owned_pos.p : nullptr, (int)ctx->q_begin, n_samples, n_lo, n_hi,
                        (const int*)ctx->nbr_pos.p, ctx->nbr_pitch, d_table, pitch, d_cnt, d_row_query);
     PCT_HIP(ctx, hipGetLastError());
@@ -889,7 +891,7 @@ int pct_launch_prefix_rows(pct_ctx* ctx, const int* d_sample_row, int64_t n_samp
 int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, float* d_K, float* d_H, float* d_H2) {
     const int blocks = (int)((rows + 255) / 256);
     if (blocks <= 0) return PCT_OK;
-    hipLaunchKernelGGL(k_curv, dim3(blocks), dim3(256), 0, ctx->stream, d_coefs, rows, d_K, d_H, d_H2);
+    PCT_LAUNCH(k_curv, dim3(blocks), dim3(256), 0, ctx->stream, d_coefs, rows, d_K, d_H, d_H2);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -897,15 +899,15 @@ int pct_launch_curvatures(pct_ctx* ctx, const float* d_coefs, int64_t rows, floa
 int pct_launch_plane_rotate(pct_ctx* ctx, const void* d_nbrs, bool f64, int64_t batch, int32_t m, double* d_out) {
     const unsigned blocks = (unsigned)((batch + 63) / 64);
     if (f64)
-        hipLaunchKernelGGL(k_plane_rotate<true>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
+        PCT_LAUNCH(k_plane_rotate<true>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
     else
-        hipLaunchKernelGGL(k_plane_rotate<false>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
+        PCT_LAUNCH(k_plane_rotate<false>, dim3(blocks), dim3(64), 0, ctx->stream, d_nbrs, batch, m, d_out);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
 
 int pct_launch_quadric_rows(pct_ctx* ctx, const float* d_pts, int64_t batch, int32_t m, float* d_coefs) {
-    hipLaunchKernelGGL(k_quadric_rows, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, d_pts, batch, m, d_coefs);
+    PCT_LAUNCH(k_quadric_rows, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, ctx->stream, d_pts, batch, m, d_coefs);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

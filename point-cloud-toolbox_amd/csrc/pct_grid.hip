@@ -582,7 +582,7 @@ static int red_reset(pct_ctx* ctx, int n_parts) {
 
 // folds the n_parts block records of the pass just launched (the result also lands in pinned host memory)
 static int red_fold(pct_ctx* ctx, int n_parts) {
-    hipLaunchKernelGGL(k_pack_final, dim3(1), dim3(kBlock), 0, ctx->stream, (const PackRed*)red_parts(ctx), n_parts,
+    PCT_LAUNCH(k_pack_final, dim3(1), dim3(kBlock), 0, ctx->stream, (const PackRed*)red_parts(ctx), n_parts,
                        (PackRed*)ctx->red.p, (PackRed*)ctx->pin);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
@@ -605,7 +605,7 @@ static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red, bool defer = false)
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));
     const int nb = grid_1d(n, kBlock * 4, 512);
     PCT_TRY(red_reset(ctx, nb));
-    hipLaunchKernelGGL(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
+    PCT_LAUNCH(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
                        ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     if (defer) {
@@ -642,7 +642,7 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     } else {
         const int nb = grid_1d(n_owned, kBlock * 4, 512);
         PCT_TRY(red_reset(ctx, nb));
-        hipLaunchKernelGGL(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream,
                            ctx->xyz_view, ctx->q_begin, ctx->q_end, red_parts(ctx));
         PCT_HIP(ctx, hipGetLastError());
         float ob[6];
@@ -671,7 +671,7 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 64));
     PCT_TRY(red_reset(ctx, nchunk));
     PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, sizeof(unsigned), ctx->stream));
-    hipLaunchKernelGGL(k_cull_pack, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end,
+    PCT_LAUNCH(k_cull_pack, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end,
                        (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
@@ -719,7 +719,7 @@ static int trim_box(pct_ctx* ctx, const PackRed& first, float* bbox) {
         for (int a = 0; a < 3; ++a) sh[a] = shift.lo[a];
         const int nblk = grid_1d(ctx->n_grid, kBlock * 4, 512);
         PCT_TRY(red_reset(ctx, nblk));
-        hipLaunchKernelGGL(k_box_stats, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_box_stats, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const float4*)ctx->pts4.p, ctx->n_grid, box, shift, red_parts(ctx));
         PCT_HIP(ctx, hipGetLastError());
         float inner[6];
@@ -733,7 +733,7 @@ int pct_pack_points_f64(pct_ctx* ctx, const double* d_xyz64) {
     const int64_t n = ctx->n;
     PCT_TRY(pct_reserve(ctx, &ctx->pts4d, (size_t)n * sizeof(double4)));
     PCT_TRY(pct_reserve(ctx, &ctx->xyz, (size_t)n * 3 * sizeof(float)));
-    hipLaunchKernelGGL(k_pack_f64, dim3(grid_1d(n, kBlock, 2048)), dim3(kBlock), 0, ctx->stream,
+    PCT_LAUNCH(k_pack_f64, dim3(grid_1d(n, kBlock, 2048)), dim3(kBlock), 0, ctx->stream,
                        d_xyz64, n, (double4*)ctx->pts4d.p, (float*)ctx->xyz.p);
     ctx->xyz_view = (const float*)ctx->xyz.p;
     PCT_HIP(ctx, hipGetLastError());
@@ -913,11 +913,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         }
         const float4* src = from_base ? (const float4*)ctx->lvl_src.p : (const float4*)ctx->pts4.p;
         if (from_base)
-            hipLaunchKernelGGL(k_hist_agg, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream, src, n, g, own_flag, ctx->own_lo,
+            PCT_LAUNCH(k_hist_agg, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream, src, n, g, own_flag, ctx->own_lo,
                                ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p, (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p,
                                (int*)ctx->cell_oth.p);
         else
-        hipLaunchKernelGGL(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_hist, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                            src, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
@@ -929,15 +929,15 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_TRY(pct_reserve(ctx, &ctx->cell_cnt, (size_t)(g.ncell + 1) * sizeof(int)));
         PCT_TRY(pct_reserve(ctx, &ctx->own_start, (size_t)(g.ncell + 1) * sizeof(int)));
         PCT_TRY(pct_reserve(ctx, &ctx->occ, ((size_t)(n_owned < g.ncell ? n_owned : g.ncell) + (size_t)n_owned / items_q + 16) * sizeof(int2)));
-        hipLaunchKernelGGL(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (int4*)ctx->scan_tmp.p, sq_part);
-        hipLaunchKernelGGL(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
+        PCT_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
                            (const unsigned long long*)sq_part, (ScanTotals*)(ctx->pin + 128));
-        hipLaunchKernelGGL(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
-        hipLaunchKernelGGL(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                            src, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
                            (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
                            g_begin, (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
@@ -1030,7 +1030,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
 }
 
 int pct_launch_gather_int(pct_ctx* ctx, const int* d_map, int* d_inout, int64_t n) {
-    hipLaunchKernelGGL(k_gather_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_map, d_inout, n);
+    PCT_LAUNCH(k_gather_int, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_map, d_inout, n);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

@@ -15,14 +15,15 @@
 // Every kernel launch of the library leaves its source position and kernel name here; the abort hook
 // (pct_api.hip: install_abort_trace) prints it, so that the log of a GPU memory fault -- ROCr aborts the process from
 // its own thread -- names the launch that preceded it (exactly the faulting one under HIP_LAUNCH_BLOCKING=1).
-extern const char* volatile pct_last_launch;
+extern const char* pct_last_launch;
 #define PCT_STR2(x) #x
 #define PCT_STR(x) PCT_STR2(x)
-#undef hipLaunchKernelGGL
-#define hipLaunchKernelGGL(kernelName, ...)                                                  \
+// (a macro of the library's own at its launch sites: HIP's hipLaunchKernelGGL is left alone, also for the rocPRIM
+// headers included after this one; the last-launch word is one relaxed atomic store, any handle's thread may write it)
+#define PCT_LAUNCH(kernelName, ...)                                                          \
     do {                                                                                     \
-        pct_last_launch = __FILE__ ":" PCT_STR(__LINE__) "  " #kernelName;                   \
-        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);                               \
+        __atomic_store_n(&pct_last_launch, __FILE__ ":" PCT_STR(__LINE__) "  " #kernelName, __ATOMIC_RELAXED); \
+        hipLaunchKernelGGL((kernelName), __VA_ARGS__);                                       \
     } while (0)
 
 // ---------------------------------------------------------------------------

@@ -1908,12 +1908,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         const bool q64_ok = ctx->has_f64 && f32_ok && far * 0x1p-23 < gg.cell * 0x1p-7 && !ctx->level_mode;
         const bool e = eps > 0, pre = !ctx->has_f64 && f32_ok, r1 = k + 1 <= pct_fast_r1_max();
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
-    hipLaunchKernelGGL((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+    PCT_LAUNCH((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;                 // tuning aid (read per call: tests flip it)
 #define PCT_FAST_PAIR(R_, E_, GRID_, BLOCK_) \
-    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+    PCT_LAUNCH((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
-    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+    PCT_LAUNCH((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         // the plain sweep of a float32 cloud with one list register: the scalar-lean kernel (k_knn_pair)
         if (pair_kernel && pre) {
             PairArgs pa = {};
@@ -1933,10 +1933,10 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
             magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
             const dim3 gridp((unsigned)((ctx->n_items + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
-            if (e && skip_dist) hipLaunchKernelGGL((k_knn_pair<true, false>), gridp, blockp, 0, ctx->stream, pa);
-            else if (e) hipLaunchKernelGGL((k_knn_pair<true, true>), gridp, blockp, 0, ctx->stream, pa);
-            else if (skip_dist) hipLaunchKernelGGL((k_knn_pair<false, false>), gridp, blockp, 0, ctx->stream, pa);
-            else hipLaunchKernelGGL((k_knn_pair<false, true>), gridp, blockp, 0, ctx->stream, pa);
+            if (e && skip_dist) PCT_LAUNCH((k_knn_pair<true, false>), gridp, blockp, 0, ctx->stream, pa);
+            else if (e) PCT_LAUNCH((k_knn_pair<true, true>), gridp, blockp, 0, ctx->stream, pa);
+            else if (skip_dist) PCT_LAUNCH((k_knn_pair<false, false>), gridp, blockp, 0, ctx->stream, pa);
+            else PCT_LAUNCH((k_knn_pair<false, true>), gridp, blockp, 0, ctx->stream, pa);
         } else
         if (q64_ok && !no_pair) {
             if (r1 && !e) PCT_FAST_PAIR64(1, false, grid1, block1);
@@ -1968,9 +1968,9 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         const int blocks = (int)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
         const int* list = exact_only ? nullptr : redo;
         if (k + 1 <= 64)
-            hipLaunchKernelGGL(k_knn_exact<1>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
+            PCT_LAUNCH(k_knn_exact<1>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
         else if (k + 1 <= 128)
-            hipLaunchKernelGGL(k_knn_exact<2>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
+            PCT_LAUNCH(k_knn_exact<2>, dim3(blocks), block, 0, ctx->stream, a, list, (const int*)redo_count);
         else
             PCT_TRY(pct_launch_knn_exact_wide(ctx, a, blocks, list, (const int*)redo_count));
         PCT_HIP(ctx, hipGetLastError());
@@ -2007,7 +2007,7 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
         // float64 clouds: the variant whose bounds are widened by the distance between a query and its float32 rounding
         // (Q64); where that distance is not small against the item's cells the proofs fail and the exact sweep answers
 #define PCT_TREE(R_, E_, Q_, GRID_, BLOCK_) \
-    hipLaunchKernelGGL((k_knn_fast<R_, E_, true, true, Q_, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+    PCT_LAUNCH((k_knn_fast<R_, E_, true, true, Q_, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         if (ctx->has_f64) {
             if (r1 && !e) PCT_TREE(1, false, true, grid1, block1);
             else if (r1) PCT_TREE(1, true, true, grid1, block1);
@@ -2024,9 +2024,9 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
     const int blocks = (32768 + kWavesPerBlock - 1) / kWavesPerBlock;        // device-side count, fixed grid
     const int* list = exact_only ? nullptr : redo;
     if (k + 1 <= 64)
-        hipLaunchKernelGGL(k_knn_exact_tree<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
+        PCT_LAUNCH(k_knn_exact_tree<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
     else
-        hipLaunchKernelGGL(k_knn_exact_tree<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
+        PCT_LAUNCH(k_knn_exact_tree<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a, list, (const int*)redo_count);
     PCT_HIP(ctx, hipGetLastError());
     ctx->knn_sorted_space = true;
     return PCT_OK;
@@ -2038,7 +2038,7 @@ int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]) {
     const int cap = k + 1 <= pct_fast_r1_max() ? kStageCap : PCT_STAGE_CAP2_HOST;
     const int blocks = (int)((ctx->n_items + 255) / 256 < 1024 ? (ctx->n_items + 255) / 256 : 1024);
     if (blocks > 0) {
-        hipLaunchKernelGGL(k_item_census, dim3(blocks), dim3(256), 0, ctx->stream, (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q,
+        PCT_LAUNCH(k_item_census, dim3(blocks), dim3(256), 0, ctx->stream, (const int2*)ctx->occ.p, ctx->n_items, ctx->items_q,
                            (const int*)ctx->cell_cnt.p, (const int*)ctx->cell_own.p, ctx->grid, k, cap, (unsigned long long*)ctx->counters.p);
         PCT_HIP(ctx, hipGetLastError());
     }
@@ -2055,9 +2055,9 @@ int pct_launch_knn_brute(pct_ctx* ctx, int32_t k, double eps) {
     const int blocks = (int)((nq + kWavesPerBlock - 1) / kWavesPerBlock);
     if (blocks > 0) {
         if (k + 1 <= 64)
-            hipLaunchKernelGGL(k_knn_brute<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
+            PCT_LAUNCH(k_knn_brute<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
         else if (k + 1 <= 128)
-            hipLaunchKernelGGL(k_knn_brute<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
+            PCT_LAUNCH(k_knn_brute<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream, a);
         else
             PCT_TRY(pct_launch_knn_brute_wide(ctx, a, blocks));
         PCT_HIP(ctx, hipGetLastError());
@@ -2072,7 +2072,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     const int64_t n_rows = ctx->q_end - ctx->q_begin;
     const int64_t total = n_rows * ctx->k;
     const int blocks = (int)((total + 255) / 256);
-    hipLaunchKernelGGL(k_export, dim3(blocks), dim3(256), 0, ctx->stream,
+    PCT_LAUNCH(k_export, dim3(blocks), dim3(256), 0, ctx->stream,
                        (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->owned_pos.p : nullptr,
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, n_rows, ctx->k, ctx->nbr_pitch, begin, end,
@@ -2083,7 +2083,7 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
 
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt) {
     const bool sorted = ctx->knn_sorted_space;
-    hipLaunchKernelGGL(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
+    PCT_LAUNCH(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
                        (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->row_of.p : nullptr,
                        sorted ? (const int*)ctx->owned_pos.p : nullptr,
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
@@ -2098,7 +2098,7 @@ int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, 
 int pct_ensure_plain_records(pct_ctx* ctx) {
     if (!ctx->qpts4_valid) {
         PCT_TRY(pct_reserve(ctx, &ctx->qpts4, (size_t)ctx->n * sizeof(float4)));
-        hipLaunchKernelGGL(k_plain_records, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream,
+        PCT_LAUNCH(k_plain_records, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream,
                            ctx->xyz_view, ctx->n, (float4*)ctx->qpts4.p);
         PCT_HIP(ctx, hipGetLastError());
         ctx->qpts4_valid = true;
@@ -2111,17 +2111,17 @@ int pct_launch_query_points(pct_ctx* ctx, const double* d_q, int64_t m, int32_t 
     const double eps2 = eps > 0 ? eps * eps : (double)INFINITY;
     const int blocks = (int)((m + kWavesPerBlock - 1) / kWavesPerBlock);
     if (k <= 64)
-        hipLaunchKernelGGL(k_query_points<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_query_points<1>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
                            (const float4*)ctx->qpts4.p, (int)ctx->n, d_q, m, k, eps2, d_idx, d_dist);
     else
-        hipLaunchKernelGGL(k_query_points<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
+        PCT_LAUNCH(k_query_points<2>, dim3(blocks), dim3(64 * kWavesPerBlock), 0, ctx->stream,
                            (const float4*)ctx->qpts4.p, (int)ctx->n, d_q, m, k, eps2, d_idx, d_dist);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
 
 int pct_launch_selftest(pct_ctx* ctx, int* d_fails) {
-    hipLaunchKernelGGL(k_selftest, dim3(1), dim3(64), 0, ctx->stream, d_fails);
+    PCT_LAUNCH(k_selftest, dim3(1), dim3(64), 0, ctx->stream, d_fails);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

@@ -7,9 +7,9 @@
 int pct_launch_knn_exact_wide(pct_ctx* ctx, const KnnArgs& a, int blocks, const int* list, const int* list_count) {
     const dim3 block(64 * kWavesPerBlock);
     if (a.k + 1 <= 256)
-        hipLaunchKernelGGL(k_knn_exact<4>, dim3(blocks), block, 0, ctx->stream, a, list, list_count);
+        PCT_LAUNCH(k_knn_exact<4>, dim3(blocks), block, 0, ctx->stream, a, list, list_count);
     else
-        hipLaunchKernelGGL(k_knn_exact<8>, dim3(blocks), block, 0, ctx->stream, a, list, list_count);
+        PCT_LAUNCH(k_knn_exact<8>, dim3(blocks), block, 0, ctx->stream, a, list, list_count);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
@@ -17,9 +17,9 @@ int pct_launch_knn_exact_wide(pct_ctx* ctx, const KnnArgs& a, int blocks, const 
 int pct_launch_knn_brute_wide(pct_ctx* ctx, const KnnArgs& a, int blocks) {
     const dim3 block(64 * kWavesPerBlock);
     if (a.k + 1 <= 256)
-        hipLaunchKernelGGL(k_knn_brute<4>, dim3(blocks), block, 0, ctx->stream, a);
+        PCT_LAUNCH(k_knn_brute<4>, dim3(blocks), block, 0, ctx->stream, a);
     else
-        hipLaunchKernelGGL(k_knn_brute<8>, dim3(blocks), block, 0, ctx->stream, a);
+        PCT_LAUNCH(k_knn_brute<8>, dim3(blocks), block, 0, ctx->stream, a);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

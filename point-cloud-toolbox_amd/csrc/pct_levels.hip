@@ -186,6 +186,7 @@ void swap_buf(T& a, T& b) { T t = a; a = b; b = t; }
 }  // namespace
 
 int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
+    *(long long*)(ctx->pin + 2048) = 0;        // rows the passes' fits hand to k_fit_svd: summed over the passes of this call
     const int64_t nq = ctx->q_end - ctx->q_begin;
     if (ctx->n >= ((int64_t)1 << 29)) return pct_fail(ctx, PCT_ERR_INVALID, "the chained sweep handles clouds below 2^29 points");
     const int pitch = (k + 3) & ~3;
@@ -219,7 +220,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
         PCT_TRY(pct_launch_knn_grid(ctx, k, eps, exact, exact ? 0 : 1));
         if (!exact) {
             // the stencil of a well-sized pass holds about 11 cells' worth of points on a surface
-            hipLaunchKernelGGL(k_classify, dim3(1024), dim3(256), 0, ctx->stream, (const int*)ctx->row_done.p, (const int*)ctx->redo_m.p,
+            PCT_LAUNCH(k_classify, dim3(1024), dim3(256), 0, ctx->stream, (const int*)ctx->row_done.p, (const int*)ctx->redo_m.p,
                                owned, (const float4*)ctx->sorted4.p, (const int*)ctx->owned_pos.p,
                                (float)log2(ctx->grid.cell), (float)(11.0 * target),
                                (float*)ctx->flag_buf.p, (float2*)ctx->dens_buf.p);
@@ -228,7 +229,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
         if (ctx->levels_fuse_fit) PCT_TRY(pct_launch_fit_pass(ctx, owned));       // before the next pass reorders the cloud
         const double t2 = debug ? tick() : 0;
         const int64_t total = owned * k;
-        hipLaunchKernelGGL(k_merge_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+        PCT_LAUNCH(k_merge_rows, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                            (const float4*)ctx->sorted4.p, (const int*)ctx->owned_pos.p, (int)ctx->q_begin,
                            (const int*)ctx->nbr_pos.p, (const float*)ctx->nbr_dist.p,
                            eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, (const int*)ctx->row_done.p, owned, k, pitch,
@@ -251,7 +252,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
         PCT_TRY(pct_reserve(ctx, &ctx->flag_buf, (size_t)ctx->n * sizeof(float)));
         PCT_TRY(pct_reserve(ctx, &ctx->dens_buf, (size_t)ctx->n * sizeof(float2)));
         PCT_TRY(pct_reserve(ctx, &ctx->stage_d, sizeof(BandStats) + 64));
-        hipLaunchKernelGGL(k_init_want, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)ctx->flag_buf.p,
+        PCT_LAUNCH(k_init_want, dim3((unsigned)((ctx->n + 255) / 256)), dim3(256), 0, ctx->stream, (float*)ctx->flag_buf.p,
                            (float2*)ctx->dens_buf.p, ctx->n);
         PCT_HIP(ctx, hipGetLastError());
         // pass 0: every owned query, cells sized as for a plain sweep
@@ -269,7 +270,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
         int64_t pending = 0;
         for (;;) {
             PCT_HIP(ctx, hipMemsetAsync(d_st, 0, sizeof(BandStats), ctx->stream));
-            hipLaunchKernelGGL(k_band_hist, dim3(512), dim3(256), 0, ctx->stream, (const float*)ctx->flag_buf.p, ctx->q_begin,
+            PCT_LAUNCH(k_band_hist, dim3(512), dim3(256), 0, ctx->stream, (const float*)ctx->flag_buf.p, ctx->q_begin,
                                ctx->q_end, log_edge0, d_st);
             PCT_HIP(ctx, hipGetLastError());
             PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 256, d_st, sizeof(BandStats), hipMemcpyDeviceToHost, ctx->stream));
@@ -294,7 +295,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
             const float hi = best + 4 >= kBins ? 0.4f * kWantExact : log_edge0 + kBinLo + 0.25f * (best + 4);
             const int init[7] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN, 0};
             PCT_HIP(ctx, hipMemcpyAsync(d_box, init, sizeof(init), hipMemcpyHostToDevice, ctx->stream));
-            hipLaunchKernelGGL(k_band_box, dim3(512), dim3(256), 0, ctx->stream, (const float*)ctx->flag_buf.p, ctx->xyz_view,
+            PCT_LAUNCH(k_band_box, dim3(512), dim3(256), 0, ctx->stream, (const float*)ctx->flag_buf.p, ctx->xyz_view,
                                ctx->q_begin, ctx->q_end, lo, hi, d_box, (unsigned*)(d_box + 6));
             PCT_HIP(ctx, hipGetLastError());
             PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 1024, d_box, sizeof(init), hipMemcpyDeviceToHost, ctx->stream));

@@ -67,12 +67,12 @@ __global__ __launch_bounds__(64) void k_mesh_final(const double* __restrict__ pa
 int pct_launch_mesh_energies(pct_ctx* ctx, const double* d_v, const int* d_tri, int64_t n_tri, const void* d_K, const void* d_H,
                              bool f64, double* d_partial, int nblk, double* d_out) {
     if (f64)
-        hipLaunchKernelGGL(k_mesh_energy<double>, dim3(nblk), dim3(kMeshBlock), 0, ctx->stream, d_v, d_tri, n_tri,
+        PCT_LAUNCH(k_mesh_energy<double>, dim3(nblk), dim3(kMeshBlock), 0, ctx->stream, d_v, d_tri, n_tri,
                            (const double*)d_K, (const double*)d_H, d_partial);
     else
-        hipLaunchKernelGGL(k_mesh_energy<float>, dim3(nblk), dim3(kMeshBlock), 0, ctx->stream, d_v, d_tri, n_tri,
+        PCT_LAUNCH(k_mesh_energy<float>, dim3(nblk), dim3(kMeshBlock), 0, ctx->stream, d_v, d_tri, n_tri,
                            (const float*)d_K, (const float*)d_H, d_partial);
-    hipLaunchKernelGGL(k_mesh_final, dim3(1), dim3(64), 0, ctx->stream, (const double*)d_partial, nblk, d_out);
+    PCT_LAUNCH(k_mesh_final, dim3(1), dim3(64), 0, ctx->stream, (const double*)d_partial, nblk, d_out);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }

@@ -373,7 +373,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     };
     tick(0);
 
-    hipLaunchKernelGGL(k_tree_codes, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, n, g.ox, g.oy, g.oz, g.inv_cell, codes_in, vals_in);
+    PCT_LAUNCH(k_tree_codes, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, n, g.ox, g.oy, g.oz, g.inv_cell, codes_in, vals_in);
     PCT_HIP(ctx, hipGetLastError());
     size_t tmp_sort = 0, tmp_max = 0, tmp_sum = 0;
     PCT_HIP(ctx, rocprim::radix_sort_pairs(nullptr, tmp_sort, codes_in, codes, vals_in, vals, nn, 0, 3 * kTreeBits, ctx->stream));
@@ -384,15 +384,15 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     PCT_TRY(pct_reserve(ctx, &ctx->tree_tmp, tmp_bytes + 256));
     PCT_HIP(ctx, rocprim::radix_sort_pairs(ctx->tree_tmp.p, tmp_sort, codes_in, codes, vals_in, vals, nn, 0, 3 * kTreeBits, ctx->stream));
     tick(1);
-    hipLaunchKernelGGL(k_tree_gather, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, (const unsigned*)vals, n,
+    PCT_LAUNCH(k_tree_gather, grid1, block, 0, ctx->stream, (const float4*)ctx->pts4.p, (const unsigned*)vals, n,
                        (float4*)ctx->sorted4.p, (int*)ctx->owned_pos.p, (int*)ctx->row_of.p,
                        ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr, ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
-    hipLaunchKernelGGL(k_tree_buckets, dim3(((1u << kTreeBucketBits) + 2 + 255) / 256), block, 0, ctx->stream, (const u64*)codes, n, (int*)ctx->tree_bucket.p);
-    hipLaunchKernelGGL(k_tree_level, grid1, block, 0, ctx->stream, (const u64*)codes, n, n_min, max_level, (unsigned char*)ctx->tree_lvl.p);
-    hipLaunchKernelGGL(k_tree_heads, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p, n, head);
+    PCT_LAUNCH(k_tree_buckets, dim3(((1u << kTreeBucketBits) + 2 + 255) / 256), block, 0, ctx->stream, (const u64*)codes, n, (int*)ctx->tree_bucket.p);
+    PCT_LAUNCH(k_tree_level, grid1, block, 0, ctx->stream, (const u64*)codes, n, n_min, max_level, (unsigned char*)ctx->tree_lvl.p);
+    PCT_LAUNCH(k_tree_heads, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p, n, head);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, rocprim::inclusive_scan(ctx->tree_tmp.p, tmp_max, head, seg_start, nn, MaxInt(), ctx->stream));
-    hipLaunchKernelGGL(k_tree_marks, grid1, block, 0, ctx->stream, (const int*)seg_start, n, items_q, marks);
+    PCT_LAUNCH(k_tree_marks, grid1, block, 0, ctx->stream, (const int*)seg_start, n, items_q, marks);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, rocprim::inclusive_scan(ctx->tree_tmp.p, tmp_sum, marks, sums, nn, rocprim::plus<u64>(), ctx->stream));
     // (segments <= items <= n; refinement appends at most one segment per point of a segment it splits)
@@ -401,7 +401,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     int* seg_pop = (int*)(seg_range + nn + 1);
     int* counts = seg_pop + nn + 1;                       // device: {items, segments, segments over the cap, their points, points per level [22]}
     long long* totals = (long long*)(ctx->pin + 2176);    // host: {items, segments}
-    hipLaunchKernelGGL(k_tree_items, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p,
+    PCT_LAUNCH(k_tree_items, grid1, block, 0, ctx->stream, (const u64*)codes, (const unsigned char*)ctx->tree_lvl.p,
                        (const int*)seg_start, (const u64*)sums, n, items_q, (int2*)ctx->occ.p, (int4*)ctx->tree_seg.p, seg_range, counts, totals);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -420,7 +420,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     if (const char* e = getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
     size_t room = (size_t)n_segs + nn / 8 + 64;           // segments the range table has room for
     PCT_TRY(pct_reserve(ctx, &ctx->tree_runs, room * 27 * sizeof(int2)));
-    hipLaunchKernelGGL(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p,
+    PCT_LAUNCH(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p,
                        (const int4*)ctx->tree_seg.p, (const int2*)seg_range, n_segs, cap, (int2*)ctx->tree_runs.p, seg_pop, counts + 2);
     PCT_HIP(ctx, hipGetLastError());
     PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 2208, counts, 26 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -450,9 +450,9 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
             pct_release(&ctx->tree_runs);
             ctx->tree_runs = bigger;
         }
-        const int64_t waves = bad_segs < 16384 ? n_segs : n_segs;
+        const int64_t waves = n_segs;
         const int blocks = (int)((waves + 3) / 4 < 8192 ? (waves + 3) / 4 : 8192);
-        hipLaunchKernelGGL(k_tree_refine, dim3(blocks), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p, (const u64*)sums, n_segs, cap, items_q,
+        PCT_LAUNCH(k_tree_refine, dim3(blocks), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p, (const u64*)sums, n_segs, cap, items_q,
                            (int4*)ctx->tree_seg.p, (const int2*)seg_range, (const int*)seg_pop, (int2*)ctx->tree_runs.p, (int2*)ctx->occ.p,
                            (unsigned char*)ctx->tree_lvl.p, counts);
         PCT_HIP(ctx, hipGetLastError());
