@@ -32,13 +32,13 @@ python - $O <<'PY'
 import json, sys
 o = sys.argv[1]
 d = json.load(open(o + "/traffic_raw.json"))
-f, w = d["k_knn_fast"]["FETCH_SIZE"], d["k_knn_fast"]["WRITE_SIZE"]
-json.dump({"kernel": "k_knn_fast<1,false,true,true,false>",
+f, w = d["k_knn_pair"]["FETCH_SIZE"], d["k_knn_pair"]["WRITE_SIZE"]
+json.dump({"kernel": "k_knn_pair<false,false> (the fused step's sweep: index table only)",
            "config": "torus 1M seed 1234 k=50, bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras",
            "FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w,
            "correction": "gfx950: FETCH_SIZE reports half of the bytes of 16 B/lane reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact",
            "hbm_bytes_per_launch": (2 * f + w) * 1024,
-           "other_kernels_KB": {k: v for k, v in d.items() if k != "k_knn_fast"},
+           "other_kernels_KB": {k: v for k, v in d.items() if k != "k_knn_pair"},
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/profile_round.sh)"},
           open(o + "/knn_traffic.json", "w"), indent=1)
 PY
