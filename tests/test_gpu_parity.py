@@ -682,6 +682,20 @@ def test_fused_entry_matches_stepwise(gpu):
     Kb, Hb = b.compute_curvature_fused(50)
     assert np.array_equal(Ka, Kb) and np.array_equal(Ha, Hb)
     assert b.last_timings["knn_ms"] > 0 and b.last_timings["fit_ms"] > 0
+    # The fused call writes no distance table (its fit never reads one): the distances it hands out on request are
+    # derived from the neighbours' records with the sweep's own fp64 expression -- the very bits plant_kdtree stores.
+    assert np.array_equal(b.neighbor_indices, a.neighbor_indices)
+    assert np.array_equal(b.dists, a.dists)
+    # ... with an eps ball (missing entries: index N, distance inf, per-row counts) and through a sampled-row read too
+    c = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    c.plant_kdtree(50, eps=0.02)
+    d = gpu["PointCloud"](points=pts, normals=np.zeros((len(pts), 0)))
+    d.compute_curvature_fused(50, eps=0.02)
+    assert np.array_equal(c.neighbor_indices, d.neighbor_indices) and np.array_equal(c.dists, d.dists)
+    assert np.array_equal(c.neighbor_counts, d.neighbor_counts) and (c.neighbor_counts < 50).any()
+    rows = np.array([0, 17, 24_999])
+    ih, dh, _ = d._handle.get_neighbor_rows(rows)
+    assert np.array_equal(ih, c.neighbor_indices[rows]) and np.array_equal(dh, c.dists[rows])
 
 
 def test_host_supplied_indices_and_validation(gpu, golden):
