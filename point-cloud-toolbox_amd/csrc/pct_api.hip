@@ -21,6 +21,24 @@ int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+extern char** environ;
+const char* pct_getenv(const char* name) {
+    struct Entry { const char* name; const char* value; };
+    static std::mutex m;
+    static Entry cache[48];
+    static int used = 0;
+    static uintptr_t fp = 0;
+    std::lock_guard<std::mutex> g(m);
+    uintptr_t now = 1469598103934665603ull;
+    for (char** e = environ; e && *e; ++e) now = (now ^ (uintptr_t)*e) * 1099511628211ull;     // setenv allocates a new string
+    if (now != fp) { fp = now; used = 0; }
+    for (int i = 0; i < used; ++i)
+        if (cache[i].name == name) return cache[i].value;
+    const char* v = getenv(name);
+    if (used < 48) cache[used++] = Entry{name, v};
+    return v;
+}
+
 void pct_release(pct_buf* b) {
     if (b->p) (void)hipFree(b->p);
     b->p = nullptr;
@@ -37,7 +55,7 @@ int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes) {
     size_t want = bytes + bytes / 8 + 256;   // a little head-room for repeated calls with growing sizes
     // (debugging: exact sizes -- every growing request moves the buffer, so code that keeps a pointer across a
     // reserve, or counts on the spare bytes behind a buffer, shows)
-    if (getenv("PCT_NO_HEADROOM")) want = bytes;
+    if (pct_getenv("PCT_NO_HEADROOM")) want = bytes;
     hipError_t e = hipMalloc(&b->p, want);
     if (e != hipSuccess) {
         b->p = nullptr;
@@ -328,8 +346,8 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     };
     if (algo == PCT_KNN_TREE) return tree_ok ? run_tree() : run_levels();
     // a handle fed a stream of similar clouds: what the census said about the last one of this size still holds
-    if (auto_req && tree_ok && ctx->auto_tree_n == ctx->n && (++ctx->auto_tree_calls & 15) != 0 && !getenv("PCT_NO_TREE") &&
-        !getenv("PCT_NO_AUTO_LEVELS")) {
+    if (auto_req && tree_ok && ctx->auto_tree_n == ctx->n && (++ctx->auto_tree_calls & 15) != 0 && !pct_getenv("PCT_NO_TREE") &&
+        !pct_getenv("PCT_NO_AUTO_LEVELS")) {
         // (the verdict holds for clouds of this size AND this bounding box, within 2 % per face -- the same test the
         // speculative cell-list build applies to "a stream of similar clouds")
         ctx->tree_check_bbox = true;
@@ -346,7 +364,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     const bool grid = algo == PCT_KNN_GRID || algo == PCT_KNN_GRID_EXACT;
     if (grid) {
         ctx->grid_skewed = false;
-        ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 16384 && !getenv("PCT_NO_TREE") && !getenv("PCT_NO_AUTO_LEVELS");
+        ctx->auto_probe = auto_req && algo == PCT_KNN_GRID && tree_ok && ctx->n >= 16384 && !pct_getenv("PCT_NO_TREE") && !pct_getenv("PCT_NO_AUTO_LEVELS");
         ctx->auto_probe_tree = ctx->auto_probe;
         const int bst = pct_build_grid(ctx, k, eps);
         ctx->auto_probe = false;
@@ -364,9 +382,9 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
         // wave-per-query exact sweep -- and how many stencil cells the others find non-empty (about 9-13 on a surface,
         // up to 27 in a volume, where the chain of cell lists does not pay).
         if (auto_req && algo == PCT_KNN_GRID && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->n >= 65536 && ctx->n < ((int64_t)1 << 29) &&
-            ctx->nonempty_cells > 0 && !getenv("PCT_NO_AUTO_LEVELS")) {
+            ctx->nonempty_cells > 0 && !pct_getenv("PCT_NO_AUTO_LEVELS")) {
             const double skew = ctx->tm.occupancy * (double)ctx->nonempty_cells / (double)ctx->n;
-            if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] occupancy %.1f, %lld non-empty cells, skew %.2f\n", ctx->tm.occupancy, (long long)ctx->nonempty_cells, skew);
+            if (pct_getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] occupancy %.1f, %lld non-empty cells, skew %.2f\n", ctx->tm.occupancy, (long long)ctx->nonempty_cells, skew);
             const double skew_min = ctx->auto_probe_tree ? 1.25 : 1.5;      // (the chain needs a wider spread to pay)
             if (!(skew > skew_min)) ctx->auto_tree_n = 0;
             if (skew > skew_min) {
@@ -374,7 +392,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
                 PCT_TRY(pct_item_census(ctx, k, c));
                 const double q = (double)(c[0] ? c[0] : 1), fail = (double)(c[1] + c[2]) / q, fine = (double)c[0] - (double)(c[1] + c[2]);
                 const double cells = fine > 0 ? (double)c[3] / fine : 27.0;
-                if (getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
+                if (pct_getenv("PCT_GRID_DEBUG")) fprintf(stderr, "[auto] census: %llu queries, %llu overflow, %llu short, %.1f non-empty stencil cells\n", c[0], c[1], c[2], cells);
                 // (the hierarchical list costs ~1.7x a uniform one whatever the density; every query the uniform list
                 // would hand to the exact sweep costs about as much as twelve it answers itself)
                 // (the hierarchical list's build -- a dozen launches, three read-backs -- costs ~0.45 ms more than the
@@ -419,7 +437,7 @@ static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
     ctx->tm.lds_overflows = (int64_t)c[1];
     ctx->tm.flushes = (int64_t)c[2];
     ctx->tm.candidate_steps = (int64_t)c[3];
-    if (getenv("PCT_TREE_DEBUG") && ctx->collect_stats)
+    if (pct_getenv("PCT_TREE_DEBUG") && ctx->collect_stats)
         fprintf(stderr, "[tree] redone %llu, up-levelled %llu, candidate steps %llu, costliest exact query: %llu steps (row %llu)\n", c[4], c[0], c[3],
                 c[6] >> 32, c[6] & 0xffffffffull);
     ctx->tm.redone_queries = (int64_t)c[4];
@@ -545,7 +563,7 @@ static int stage_neighbour_rows(pct_ctx* ctx, const int32_t* idx, const int32_t*
     if (!idx || rows <= 0 || k < 1 || k > 4096) return pct_fail(ctx, PCT_ERR_INVALID, "bad neighbour rows");
     // host-side validation: the reference raises IndexError on such rows (pct:640).  PCT_TRUST_ROWS=1 skips it (test
     // hook for the kernel's own guard: an entry outside the cloud is clamped there and the row reads NaN)
-    const bool trust = getenv("PCT_TRUST_ROWS") != nullptr;
+    const bool trust = pct_getenv("PCT_TRUST_ROWS") != nullptr;
     for (int64_t r = 0; r < rows && !trust; ++r) {
         const int m = count ? count[r] : k;
         if (m < 0 || m > k) return pct_fail(ctx, PCT_ERR_INVALID, "row %lld: count %d outside [0,%d]", (long long)r, m, k);

@@ -178,7 +178,7 @@ int pct_comm_allgather_f32(pct_ctx* ctx, const void* dev_send, void* dev_recv, c
     }
     enum { AG = 0, PADDED = 1, BCAST = 2 };
     int mode = equal ? AG : PADDED;
-    if (const char* f = getenv("PCT_COMM_FORCE")) {
+    if (const char* f = pct_getenv("PCT_COMM_FORCE")) {
         if (!strcmp(f, "bcast")) mode = BCAST;
         else if (!strcmp(f, "padded")) mode = PADDED;
         else if (!strcmp(f, "allgather") && equal) mode = AG;

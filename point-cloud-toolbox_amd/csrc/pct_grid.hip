@@ -786,14 +786,14 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     float bbox[6];
     PackRed red;
     Box3 kept_box = {};
-    const bool try_cull = !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !getenv("PCT_NO_CULL");
+    const bool try_cull = !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !pct_getenv("PCT_NO_CULL");
     ctx->tm.grid_iters = 0;
     // Speculation: a handle fed a stream of similar clouds builds the cell list over the (trimmed) box of the previous
     // call without waiting for the new bounding box -- any box is a valid grid box, points outside are clamped into
     // the boundary cells -- and checks the new box at the synchronisation that ends the first pass.  One host round
     // trip less per build.
     bool spec = !try_cull && !own_flag && !ctx->level_mode && ctx->hint_edge > 0 && ctx->spec_valid && ctx->spec_n == ctx->n &&
-                !getenv("PCT_NO_SPEC");
+                !pct_getenv("PCT_NO_SPEC");
     // later passes of the density-adaptive sweep: the points in the cell order of its first pass, and that pass's box
     const bool from_base = own_flag && ctx->lvl_src_valid;
     if (from_base) {
@@ -849,7 +849,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
     int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
-    if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
+    if (const char* e = pct_getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));
     PCT_TRY(pct_reserve(ctx, &ctx->row_of, (size_t)((own_flag ? n : n_owned) + 1) * sizeof(int)));
@@ -921,7 +921,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            src, n, g, g_begin, g_end, own_flag, ctx->own_lo, ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p,
                            (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr);
         nblk = (int)((g.ncell + kScanTile - 1) / kScanTile);
-        if (getenv("PCT_GRID_DEBUG"))
+        if (pct_getenv("PCT_GRID_DEBUG"))
             fprintf(stderr, "[grid] pass %d: n %lld owned %lld edge %g dims %d x %d x %d = %lld cells (%d scan tiles), box [%g %g %g]-[%g %g %g]\n", it,
                     (long long)n, (long long)n_owned, a, g.nx, g.ny, g.nz, (long long)g.ncell, nblk, bbox[0], bbox[1], bbox[2], bbox[3], bbox[4], bbox[5]);
         PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, (size_t)(nblk + 1) * sizeof(int4) + (size_t)nblk * sizeof(unsigned long long)));
@@ -989,7 +989,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         g.lim_lo[ax] = ctx->culled ? ((double)kept_box.lo[ax] - o) * g.inv_cell : -INFINITY;
         g.lim_hi[ax] = ctx->culled ? ((double)kept_box.hi[ax] - o) * g.inv_cell : INFINITY;
     }
-    if (getenv("PCT_GRID_DEBUG"))
+    if (pct_getenv("PCT_GRID_DEBUG"))
         fprintf(stderr, "[grid] box [%g %g %g]-[%g %g %g] edge %g dims %d x %d x %d = %lld cells, %d passes, occupancy %.1f, items %d\n", bbox[0],
                 bbox[1], bbox[2], bbox[3], bbox[4], bbox[5], g.cell, g.nx, g.ny, g.nz, (long long)g.ncell, iters, m_last, tot.y);
     if (ctx->level_mode && !own_flag)                    // first pass of a density-adaptive sweep: its (trimmed) box serves the later ones

@@ -182,6 +182,10 @@ struct pct_ctx {
 };
 
 int pct_fail(pct_ctx* ctx, int code, const char* fmt, ...);
+// getenv() for the library's switches (PCT_*), cached: a fused call used to make ~20 getenv() scans of the environment
+// (~6 us per step).  The cache is dropped whenever the environment block changes (a fingerprint of its string pointers,
+// ~50 loads per lookup), so tests and tools that flip a switch between calls keep working.  `name` must be a literal.
+const char* pct_getenv(const char* name);
 void pct_comm_release(pct_ctx* ctx);
 
 // The fast sweep sorts <= 64 survivors in one register per lane (R = 1) or <= 128 in two (R = 2).  R = 1 would hold

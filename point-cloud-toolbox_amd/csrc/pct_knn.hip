@@ -1877,9 +1877,9 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
     const double c2_ = ctx->grid.cell * ctx->grid.cell;                // (the float32 pre-selection's range, see f32_ok below)
     const bool f32_ok_ = c2_ > 1e-30 && c2_ < 1e30 && (!(eps > 0) || eps * eps > 1e-36);
     const bool pair_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
-                             k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !getenv("PCT_NO_PAIR") &&
-                             !getenv("PCT_NO_PAIR_KERNEL");
-    const bool skip_dist = pair_kernel && ctx->skip_dist_req && !getenv("PCT_KEEP_DIST");
+                             k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !pct_getenv("PCT_NO_PAIR") &&
+                             !pct_getenv("PCT_NO_PAIR_KERNEL");
+    const bool skip_dist = pair_kernel && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
     if (phase != 2) {
         PCT_TRY(reserve_table(ctx, k, eps, !skip_dist));
         PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
@@ -1909,7 +1909,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
         const bool e = eps > 0, pre = !ctx->has_f64 && f32_ok, r1 = k + 1 <= pct_fast_r1_max();
 #define PCT_FAST(R_, E_, P_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, P_>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        const bool no_pair = getenv("PCT_NO_PAIR") != nullptr;                 // tuning aid (read per call: tests flip it)
+        const bool no_pair = pct_getenv("PCT_NO_PAIR") != nullptr;                 // tuning aid (read per call: tests flip it)
 #define PCT_FAST_PAIR(R_, E_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
@@ -1999,7 +1999,7 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
     int* redo = (int*)ctx->redo.p;
     const int2* items = (const int2*)ctx->occ.p;
     const bool r1 = k + 1 <= pct_fast_r1_max();
-    const bool exact_only = getenv("PCT_TREE_EXACT_ONLY") != nullptr;        // testing: every query through the exact sweep
+    const bool exact_only = pct_getenv("PCT_TREE_EXACT_ONLY") != nullptr;        // testing: every query through the exact sweep
     if (ctx->n_items > 0 && !exact_only) {
         const dim3 grid1((unsigned)((ctx->n_items + kFastWaves<1> - 1) / kFastWaves<1>)), block1(64 * kFastWaves<1>);
         const dim3 grid2((unsigned)((ctx->n_items + kFastWaves<2> - 1) / kFastWaves<2>)), block2(64 * kFastWaves<2>);

@@ -194,7 +194,7 @@ int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
     const double target = factor * (k + 1);
     constexpr int kMaxPasses = 14;
     const int64_t enough = nq / 256 > 1024 ? nq / 256 : 1024;      // leftovers of this size go to the exact sweep
-    const bool debug = getenv("PCT_LEVELS_DEBUG") != nullptr;
+    const bool debug = pct_getenv("PCT_LEVELS_DEBUG") != nullptr;
 
     ctx->no_cull = true;            // the merged table and the public-space fit need every point packed
     ctx->level_mode = true;

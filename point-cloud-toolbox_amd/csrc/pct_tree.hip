@@ -328,10 +328,10 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     g.ncell = 0;
     for (int a = 0; a < 3; ++a) { g.lim_lo[a] = -INFINITY; g.lim_hi[a] = INFINITY; }
     int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
-    if (const char* e = getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }
+    if (const char* e = pct_getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }
     ctx->items_q = items_q;
     double f_min = 0.45;
-    if (const char* e = getenv("PCT_TREE_NMIN")) { const double v = atof(e); if (v > 0.05 && v < 8) f_min = v; }   // tuning aid
+    if (const char* e = pct_getenv("PCT_TREE_NMIN")) { const double v = atof(e); if (v > 0.05 && v < 8) f_min = v; }   // tuning aid
     int n_min = (int)lrint(f_min * (k + 1));
     n_min = n_min < 2 ? 2 : n_min;
     int max_level = kTreeBits;
@@ -362,7 +362,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     u64* marks = (u64*)ctx->tree_marks.p;
     u64* sums = marks + nn;
     const dim3 grid1((unsigned)((n + 255) / 256)), block(256);
-    const bool debug = getenv("PCT_TREE_DEBUG") != nullptr;
+    const bool debug = pct_getenv("PCT_TREE_DEBUG") != nullptr;
     double t_mark[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const auto tick = [&](int i) {
         if (!debug) return;
@@ -417,7 +417,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
 #define PCT_TREE_CAP2 1024
 #endif
     int cap = k + 1 <= pct_fast_r1_max() ? PCT_TREE_CAP : PCT_TREE_CAP2;
-    if (const char* e = getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
+    if (const char* e = pct_getenv("PCT_TREE_SPLIT")) { const int v = atoi(e); if (v >= 64 && v <= cap) cap = v; }       // tuning aid
     size_t room = (size_t)n_segs + nn / 8 + 64;           // segments the range table has room for
     PCT_TRY(pct_reserve(ctx, &ctx->tree_runs, room * 27 * sizeof(int2)));
     PCT_LAUNCH(k_tree_stencil, dim3((unsigned)((n_segs * 32 + 255) / 256)), block, 0, ctx->stream, (const u64*)codes, (const int*)ctx->tree_bucket.p,
@@ -440,7 +440,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
         ctx->tree_two_level_share = tot > 0 ? (double)best2 / (double)tot : 1.0;
     }
     const int64_t bad_segs = ((const int*)(ctx->pin + 2208))[2], bad_pts = ((const int*)(ctx->pin + 2208))[3];
-    if (bad_segs > 0 && !getenv("PCT_TREE_NO_REFINE")) {
+    if (bad_segs > 0 && !pct_getenv("PCT_TREE_NO_REFINE")) {
         if ((size_t)(n_segs + bad_pts) > room) {          // rare: most of the cloud is being split -- a larger table, contents kept
             room = (size_t)(n_segs + bad_pts) + 64;
             pct_buf bigger;
