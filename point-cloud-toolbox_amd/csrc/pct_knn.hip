@@ -1208,6 +1208,7 @@ __device__ __forceinline__ void sort_pair_asm(unsigned& ea, unsigned& eb, const 
 
 struct PairArgs {
     const float4* pts;        // cell-sorted candidate records {x, y, z, public index}
+    const double4* ptsd;      // Q64: the native float64 coordinates in the same order (queries; the candidates stay float32, pct:74)
     const int* cell_start;
     const int* cell_own;
     const int* own_start;
@@ -1244,8 +1245,12 @@ struct PairLds {
 // waited for the slowest, 4.6 of 6 wave slots per SIMD filled; 0.392 -> 0.379 ms)
 constexpr int kPairWaves = PCT_PAIR_WAVES;
 
-template <bool EPS, bool DIST>
-__global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
+// Q64: a float64 cloud -- the candidates are the float32-rounded points (the reference's tree data, pct:74), a query is the
+// native float64 point (pct:83): the float32 pre-selection measures from the query ROUNDED to float32, a point
+// eq = |q64 - q32| away from the true one, and every bound taken from it moves by eq (see k_knn_fast); exact keys and
+// distances use the float64 query.
+template <bool EPS, bool DIST, bool Q64 = false>
+__global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(PairArgs a) {
     constexpr int CAP = kPairCap, LIST = 64, SLOT_BITS = 6, KEY_BITS = 32 - SLOT_BITS;
     __shared__ PairLds s_lds[kPairWaves];
     const int w = kPairWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1281,7 +1286,20 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
     }
     // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
     float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < nq) my_q = a.pts[qs + lane];
+    double my_qx = 0., my_qy = 0., my_qz = 0.;
+    float my_eq = 0.f;       // Q64: distance between the float64 query and its float32 rounding, rounded up
+    if (lane < nq) {
+        my_q = a.pts[qs + lane];
+        if constexpr (Q64) {
+            const double4 qd = a.ptsd[qs + lane];
+            my_qx = qd.x; my_qy = qd.y; my_qz = qd.z;
+        }
+    }
+    if constexpr (Q64) {
+        const double ex = my_qx - (double)my_q.x, ey = my_qy - (double)my_q.y, ez = my_qz - (double)my_q.z;
+        my_eq = (float)sqrt((ex * ex + ey * ey) + ez * ez) * (1.0f + 0x1p-22f);
+        if (!(my_eq >= 0.f)) my_eq = INFINITY;
+    }
     // exclusive prefix of the run lengths over lanes 0..8 = first flat slot of every run; m = staged candidates
     int my_pre = 0, m = 0;
     {
@@ -1361,15 +1379,17 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
     constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
     unsigned my_gkey;                                     // per query (lane l = query l): the largest key the stencil vouches for
     {
-        const double gx = ((double)my_q.x - a.g.ox) * a.g.inv_cell - cx;
-        const double gy = ((double)my_q.y - a.g.oy) * a.g.inv_cell - cy;
-        const double gz = ((double)my_q.z - a.g.oz) * a.g.inv_cell - cz;
+        const double lqx = Q64 ? my_qx : (double)my_q.x, lqy = Q64 ? my_qy : (double)my_q.y, lqz = Q64 ? my_qz : (double)my_q.z;
+        const double gx = (lqx - a.g.ox) * a.g.inv_cell - cx;
+        const double gy = (lqy - a.g.oy) * a.g.inv_cell - cy;
+        const double gz = (lqz - a.g.oz) * a.g.inv_cell - cz;
         const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
         my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
     const float cell2f = (float)(edge * edge);
     const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
+    const double eps1 = EPS ? sqrt(eps2) * (1.0 + 0x1p-50) : 0.0;       // eps itself, rounded up (Q64)
     float t_prev_f = 0.f;                                 // threshold of the previous query of this item (0 = none yet)
     unsigned long long redo_mask = 0ull;                  // queries of this item the exact sweep has to take
 
@@ -1394,6 +1414,12 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
             const float bx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qj));
             const float by = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qj));
             const float bz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qj));
+            // the queries the exact keys measure from: the float32 record widened, or (Q64) the native coordinates
+            const auto rl64 = [&](double v, int l) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+            };
+            const double qax = Q64 ? rl64(my_qx, qi) : (double)ax, qay = Q64 ? rl64(my_qy, qi) : (double)ay, qaz = Q64 ? rl64(my_qz, qi) : (double)az;
+            const double qbx = Q64 ? rl64(my_qx, qj) : (double)bx, qby = Q64 ? rl64(my_qy, qj) : (double)by, qbz = Q64 ? rl64(my_qz, qj) : (double)bz;
             // ---- float32 squared distances of ALL staged candidates to both queries (one set of LDS reads) --------
             float ap_a[NBU], ap_b[NBU];
 #pragma unroll
@@ -1419,18 +1445,29 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
             }
             // ---- thresholds: k+1 <= #(d < T) <= LIST for each query, never beyond the eps ball.  Lane 0 searches for
             // query a, lane 1 for query b: the counts are wave-wide ballots, the secant arithmetic is per lane.
-            const float T_init = eps2a;                       // +inf without eps
+            // +inf without eps; Q64: exact d < eps  =>  d' < eps + eq, per query (lane 0: a, lanes >= 1: b)
+            float T_init = eps2a;
+            float Ti_a = eps2a, Ti_b = eps2a;
+            const float eq_a = Q64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qi)) : 0.f;
+            const float eq_b = Q64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qj)) : 0.f;
+            const float v_eq = lane == 0 ? eq_a : eq_b;
+            if constexpr (EPS && Q64) {
+                const double ee = eps1 + (double)v_eq;
+                T_init = (float)fmin(ee * ee * (1.0 + 0x1p-18), 3.0e38);
+                Ti_a = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T_init), 0));
+                Ti_b = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(T_init), 1));
+            }
             int tot_a = m, tot_b = m;
             if constexpr (EPS) {
                 tot_a = tot_b = 0;
 #pragma unroll
                 for (int b = 0; b < NBU; ++b) {
-                    tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < T_init));
-                    tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < T_init));
+                    tot_a += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_a[b] < Ti_a));
+                    tot_b += (int)__popcll(__builtin_amdgcn_ballot_w64(ap_b[b] < Ti_b));
                 }
             }
             const bool need_a = tot_a > LIST, need_b = live_b && tot_b > LIST;
-            float T_a = T_init, T_b = T_init;
+            float T_a = Ti_a, T_b = Ti_b;
             int cnt_a = tot_a, cnt_b = tot_b;
             bool ok_a = true, ok_b = live_b;
             unsigned bkey_a = 0xFFFFFFFFu, bkey_b = 0xFFFFFFFFu;     // exact keys of the candidates the pre-selection cut are >= bkey
@@ -1481,7 +1518,13 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
                 cnt_b = __builtin_amdgcn_readlane(v_cnt, 1);
                 // smallest exact key a candidate cut by the float32 threshold T can have: its float32 d^2 >= T means the
                 // exact d^2 >= T (1 - 2^-20) (arithmetic error of the packed evaluation)
-                const unsigned v_bkey = (unsigned)fmin((double)v_T * (1.0 - 0x1p-20) * scale, 4294967294.0);
+                double lo2 = (double)v_T * (1.0 - 0x1p-20);
+                if constexpr (Q64) {
+                    // (sqrt(L) - eq)^2 >= L - 2 eq sqrt(L); an upper bound of the root is enough: float32 root, rounded up
+                    const double root_up = (double)__builtin_sqrtf(v_T) * (1.0 + 0x1p-21);
+                    lo2 = fmax(lo2 - 2.0 * (double)v_eq * root_up, 0.0);
+                }
+                const unsigned v_bkey = (unsigned)fmin(lo2 * scale, 4294967294.0);
                 ok_a = (fm & 1u) != 0u && (!need_a || T_a >= 1e-30f);
                 ok_b = live_b && (fm & 2u) != 0u && (!need_b || T_b >= 1e-30f);
                 if (need_a && ok_a) { t_prev_f = T_a; bkey_a = (unsigned)__builtin_amdgcn_readlane((int)v_bkey, 0); }
@@ -1544,8 +1587,8 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
             if (false)
 #endif
             {
-                const double dxa = (double)L.cx[ja] - (double)ax, dya = (double)L.cy[ja] - (double)ay, dza = (double)L.cz[ja] - (double)az;
-                const double dxb = (double)L.cx[jb] - (double)bx, dyb = (double)L.cy[jb] - (double)by, dzb = (double)L.cz[jb] - (double)bz;
+                const double dxa = (double)L.cx[ja] - qax, dya = (double)L.cy[ja] - qay, dza = (double)L.cz[ja] - qaz;
+                const double dxb = (double)L.cx[jb] - qbx, dyb = (double)L.cy[jb] - qby, dzb = (double)L.cz[jb] - qbz;
                 const double d2a = (dxa * dxa + dya * dya) + dza * dza;
                 const double d2b = (dxb * dxb + dyb * dyb) + dzb * dzb;
                 if constexpr (DIST) {
@@ -1595,7 +1638,7 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
                 }
                 if (__builtin_expect((cm_a | cm_b) != 0ull, 0)) {
                     if (ok_a && cm_a != 0ull) {
-                        const double ux = (double)ax, uy = (double)ay, uz = (double)az;
+                        const double ux = qax, uy = qay, uz = qaz;
                         const bool done = order_equal_keys<1, SLOT_BITS>(&e_a, a.pts,
                             [&](unsigned at) {
                                 const int j = (int)L.pend[at] & (CAP - 1);
@@ -1606,7 +1649,7 @@ __global__ __launch_bounds__(64 * kPairWaves, 6) void k_knn_pair(PairArgs a) {
                         if (!done) { redo_mask |= 1ull << qi; ok_a = false; }
                     }
                     if (ok_b && cm_b != 0ull) {
-                        const double ux = (double)bx, uy = (double)by, uz = (double)bz;
+                        const double ux = qbx, uy = qby, uz = qbz;
                         const bool done = order_equal_keys<1, SLOT_BITS>(&e_b, a.pts,
                             [&](unsigned at) {
                                 const int j = (int)L.pend_b[at] & (CAP - 1);
@@ -1727,14 +1770,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_query_points(const floa
 // The float32 distance of a table entry, from the two records: the sweep's own expression -- fp64 ((dx^2 + dy^2) +
 // dz^2) without contraction, correctly rounded root, one rounding to float32 (pct:78) -- so a table written without
 // distances (the fused curvature call) yields the very bits the sweep would have stored.
-__device__ __forceinline__ float table_distance(const float4 q, const float4 c) {
-    const double dx = (double)c.x - (double)q.x, dy = (double)c.y - (double)q.y, dz = (double)c.z - (double)q.z;
+__device__ __forceinline__ float table_distance(const float4* pts, const double4* ptsd, int qpos, const float4 c) {
+    double qx, qy, qz;                 // the query as the sweep measured from it: native float64 coordinates where the cloud has them (pct:83)
+    if (ptsd) { const double4 q = ptsd[qpos]; qx = q.x; qy = q.y; qz = q.z; }
+    else { const float4 q = pts[qpos]; qx = (double)q.x; qy = (double)q.y; qz = (double)q.z; }
+    const double dx = (double)c.x - qx, dy = (double)c.y - qy, dz = (double)c.z - qz;
     return (float)sqrt((dx * dx + dy * dy) + dz * dz);
 }
 
 // neighbour table -> public (rows,k) arrays for public rows [begin,end).  owned_pos == nullptr: the table came
 // from the exhaustive sweep (row = public index - q_begin, entries = public indices).
-__global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const int* __restrict__ owned_pos, int q_begin,
+__global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, const double4* __restrict__ ptsd, const int* __restrict__ owned_pos, int q_begin,
                                                 const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
                                                 const int* __restrict__ nbr_cnt, int64_t n, int64_t n_rows, int k, int pitch,
                                                 int64_t begin, int64_t end, int* __restrict__ idx_out,
@@ -1749,12 +1795,12 @@ __global__ __launch_bounds__(256) void k_export(const float4* __restrict__ pts, 
     const int pos = nbr_pos[row * pitch + j];
     const float4 c = pos < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pts[pos];
     if (idx_out) idx_out[o] = pos < 0 ? (int)n : __float_as_int(c.w);
-    if (dist_out) dist_out[o] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts[owned_pos[row]], c);
+    if (dist_out) dist_out[o] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts, ptsd, owned_pos[row], c);
     if (cnt_out && j == 0) cnt_out[pub - begin] = nbr_cnt ? nbr_cnt[row] : k;
 }
 
 // the same for an explicit list of public rows (one block per listed row)
-__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const int* __restrict__ row_of, const int* __restrict__ owned_pos, int q_begin,
+__global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ pts, const double4* __restrict__ ptsd, const int* __restrict__ row_of, const int* __restrict__ owned_pos, int q_begin,
                                                      const int* __restrict__ nbr_pos, const float* __restrict__ nbr_dist,
                                                      const int* __restrict__ nbr_cnt, int64_t n, int k, int pitch,
                                                      const int64_t* __restrict__ rows, int* __restrict__ idx_out,
@@ -1766,7 +1812,7 @@ __global__ __launch_bounds__(128) void k_export_rows(const float4* __restrict__ 
         const int pos = nbr_pos[row * pitch + j];
         const float4 c = pos < 0 ? make_float4(0.f, 0.f, 0.f, 0.f) : pts[pos];
         if (idx_out) idx_out[r * k + j] = pos < 0 ? (int)n : __float_as_int(c.w);
-        if (dist_out) dist_out[r * k + j] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts[owned_pos[row]], c);
+        if (dist_out) dist_out[r * k + j] = nbr_dist ? nbr_dist[row * pitch + j] : pos < 0 ? INFINITY : table_distance(pts, ptsd, owned_pos[row], c);
     }
     if (cnt_out && threadIdx.x == 0) cnt_out[r] = nbr_cnt ? nbr_cnt[row] : k;
 }
@@ -1876,7 +1922,13 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
     // same bits from the positions when asked).
     const double c2_ = ctx->grid.cell * ctx->grid.cell;                // (the float32 pre-selection's range, see f32_ok below)
     const bool f32_ok_ = c2_ > 1e-30 && c2_ < 1e30 && (!(eps > 0) || eps * eps > 1e-36);
-    const bool pair_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
+    // (float64 clouds take it too unless the rounding distance of the queries is not small against a cell edge --
+    // coordinates so large that float32 resolves them barely finer than the cells: see q64_ok below)
+    const pct_grid& gg_ = ctx->grid;
+    const double far_ = fmax(fmax(fabs(gg_.ox), fabs(gg_.ox + gg_.nx * gg_.cell)),
+                             fmax(fmax(fabs(gg_.oy), fabs(gg_.oy + gg_.ny * gg_.cell)), fmax(fabs(gg_.oz), fabs(gg_.oz + gg_.nz * gg_.cell))));
+    const bool q64_ok_ = !ctx->has_f64 || far_ * 0x1p-23 < gg_.cell * 0x1p-7;
+    const bool pair_kernel = !exact_only && phase == 0 && q64_ok_ && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
                              k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !pct_getenv("PCT_NO_PAIR") &&
                              !pct_getenv("PCT_NO_PAIR_KERNEL");
     const bool skip_dist = pair_kernel && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
@@ -1915,9 +1967,9 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         // the plain sweep of a float32 cloud with one list register: the scalar-lean kernel (k_knn_pair)
-        if (pair_kernel && pre) {
+        if (pair_kernel) {
             PairArgs pa = {};
-            pa.pts = a.pts; pa.cell_start = a.cell_start; pa.cell_own = a.cell_own; pa.own_start = a.own_start;
+            pa.pts = a.pts; pa.ptsd = a.ptsd; pa.cell_start = a.cell_start; pa.cell_own = a.cell_own; pa.own_start = a.own_start;
             pa.items = items;
             pa.nbr_pos = a.nbr_pos; pa.nbr_dist = a.nbr_dist; pa.nbr_cnt = a.nbr_cnt;
             pa.redo = redo; pa.redo_count = redo_count; pa.counters = a.counters;
@@ -1933,6 +1985,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
             magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
             const dim3 gridp((unsigned)((ctx->n_items + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
+            if (ctx->has_f64) {
+                if (e && skip_dist) PCT_LAUNCH((k_knn_pair<true, false, true>), gridp, blockp, 0, ctx->stream, pa);
+                else if (e) PCT_LAUNCH((k_knn_pair<true, true, true>), gridp, blockp, 0, ctx->stream, pa);
+                else if (skip_dist) PCT_LAUNCH((k_knn_pair<false, false, true>), gridp, blockp, 0, ctx->stream, pa);
+                else PCT_LAUNCH((k_knn_pair<false, true, true>), gridp, blockp, 0, ctx->stream, pa);
+            } else
             if (e && skip_dist) PCT_LAUNCH((k_knn_pair<true, false>), gridp, blockp, 0, ctx->stream, pa);
             else if (e) PCT_LAUNCH((k_knn_pair<true, true>), gridp, blockp, 0, ctx->stream, pa);
             else if (skip_dist) PCT_LAUNCH((k_knn_pair<false, false>), gridp, blockp, 0, ctx->stream, pa);
@@ -2073,7 +2131,8 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
     const int64_t total = n_rows * ctx->k;
     const int blocks = (int)((total + 255) / 256);
     PCT_LAUNCH(k_export, dim3(blocks), dim3(256), 0, ctx->stream,
-                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->owned_pos.p : nullptr,
+                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted && ctx->has_f64 ? (const double4*)ctx->sorted4d.p : nullptr,
+                       sorted ? (const int*)ctx->owned_pos.p : nullptr,
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, n_rows, ctx->k, ctx->nbr_pitch, begin, end,
                        d_idx, d_dist, d_cnt);
@@ -2084,7 +2143,8 @@ int pct_launch_export_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_
 int pct_launch_export_rows(pct_ctx* ctx, const int64_t* d_rows, int64_t n_rows, int32_t* d_idx, float* d_dist, int32_t* d_cnt) {
     const bool sorted = ctx->knn_sorted_space;
     PCT_LAUNCH(k_export_rows, dim3((unsigned)n_rows), dim3(128), 0, ctx->stream,
-                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted ? (const int*)ctx->row_of.p : nullptr,
+                       (const float4*)(sorted ? ctx->sorted4.p : ctx->pts4.p), sorted && ctx->has_f64 ? (const double4*)ctx->sorted4d.p : nullptr,
+                       sorted ? (const int*)ctx->row_of.p : nullptr,
                        sorted ? (const int*)ctx->owned_pos.p : nullptr,
                        (int)ctx->q_begin, (const int*)ctx->nbr_pos.p, ctx->dist_valid ? (const float*)ctx->nbr_dist.p : nullptr,
                        ctx->eps > 0 ? (const int*)ctx->nbr_cnt.p : nullptr, ctx->n, ctx->k, ctx->nbr_pitch, d_rows, d_idx,

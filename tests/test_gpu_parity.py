@@ -696,6 +696,15 @@ def test_fused_entry_matches_stepwise(gpu):
     rows = np.array([0, 17, 24_999])
     ih, dh, _ = d._handle.get_neighbor_rows(rows)
     assert np.array_equal(ih, c.neighbor_indices[rows]) and np.array_equal(dh, c.dists[rows])
+    # a float64 cloud: the derived distance is measured from the NATIVE float64 query (pct:83), as the sweep's is
+    p64 = pts.astype(np.float64) * 1.000000123 + 1e-9
+    e = gpu["PointCloud"](points=p64, normals=np.zeros((len(pts), 0)))
+    e.plant_kdtree(50)
+    f = gpu["PointCloud"](points=p64, normals=np.zeros((len(pts), 0)))
+    f.compute_curvature_fused(50)
+    ref = oracle.knn(p64, 50)
+    assert np.array_equal(e.neighbor_indices, ref[0]) and np.array_equal(e.dists, ref[1])
+    assert np.array_equal(f.neighbor_indices, ref[0]) and np.array_equal(f.dists, ref[1])
 
 
 def test_host_supplied_indices_and_validation(gpu, golden):
