@@ -174,18 +174,23 @@ CONFIGS = {
 }
 
 
-def verify_against_golden(handle, cfg, lo, hi, oracle):
-    """Sampled reference rows that fall into [lo, hi): indices and distances bit for bit, K/H at 1e-5."""
+def verify_against_golden(handle, cfg, lo, hi, oracle, kh=None):
+    """Sampled reference rows that fall into [lo, hi): indices and distances bit for bit, K/H at 1e-5.
+    kh: (K, H) of rows [lo, hi) as a slab-ownership step returned them (the rank holds no neighbour rows of its index
+    range then: K and H only)."""
     g = dict(np.load(os.path.join(GOLDEN, CONFIGS[cfg]["golden"])))
     sel = (g["rows"] >= lo) & (g["rows"] < hi)
     rows = g["rows"][sel]
     if len(rows) == 0:
         return 0
-    idx, dist, cnt = handle.get_neighbor_rows(rows)
-    if "count" in g:
-        assert np.array_equal(cnt, g["count"][sel]), "valid-neighbour counts differ from the reference"
-    assert np.array_equal(idx, g["idx"][sel]) and np.array_equal(dist, g["dists"][sel]), "neighbour rows differ from the reference"
-    _, K, H, _ = handle.get_fit(lo, hi, coefs=False, H2=False)
+    if kh is None:
+        idx, dist, cnt = handle.get_neighbor_rows(rows)
+        if "count" in g:
+            assert np.array_equal(cnt, g["count"][sel]), "valid-neighbour counts differ from the reference"
+        assert np.array_equal(idx, g["idx"][sel]) and np.array_equal(dist, g["dists"][sel]), "neighbour rows differ from the reference"
+        _, K, H, _ = handle.get_fit(lo, hi, coefs=False, H2=False)
+    else:
+        K, H = kh
     fK, fH = 1e-2 * np.nanmax(np.abs(g["K"])), 1e-2 * np.nanmax(np.abs(g["H"]))
     assert oracle.curvature_tolerance_ok(K[rows - lo], g["K"][sel], fK).all(), "K outside 1e-5 of the reference"
     assert oracle.curvature_tolerance_ok(H[rows - lo], g["H"][sel], fH).all(), "H outside 1e-5 of the reference"
@@ -271,6 +276,9 @@ def main():
     ap.add_argument("--k", type=int, default=0, help="neighbours (default: the config's)")
     ap.add_argument("--config", choices=sorted(CONFIGS), default="c3")
     ap.add_argument("--verify", action="store_true", help="check the sampled reference goldens on every rank")
+    ap.add_argument("--ownership", choices=("auto", "range", "slab"), default="auto",
+                    help="multi-GPU: which rows a rank answers -- its index range, or a slab of equal population along the cloud's "
+                         "longest axis (clouds in no spatial order; auto: slab for c4, range otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip first-call / end-to-end / lattice / repeat measurements")
     args = ap.parse_args()
@@ -324,13 +332,14 @@ def main():
         handle.synchronize()
 
     sc = None
+    ownership = args.ownership if args.ownership != "auto" else ("slab" if args.config == "c4" else "range")
     if not dist_mode:
         handle.set_points(local)                              # resident before the timed region
 
         def step():
             handle.curvature(k, eps, _capi.KNN_GRID)
     else:
-        sc = ShardedCurvature(n_total, k, rank, world, eps=eps, handle=handle, exchange=exchange)
+        sc = ShardedCurvature(n_total, k, rank, world, eps=eps, handle=handle, exchange=exchange, ownership=ownership)
         # the local shard is resident on the device before the timed region; the exchange is part of the step.
         # Two gather buffers: the exchange of step i+1 (RCCL, exchange stream) overlaps the kernels of step i (compute
         # stream), as in a pipeline over a stream of clouds.  Every timed step still contains one full exchange and one
@@ -378,7 +387,7 @@ def main():
         if args.config == "c3" and world > 1:
             mine = 0                                          # the scan-ordered weak-scaling cloud has no reference sample
         else:
-            mine = verify_against_golden(handle, args.config, lo, hi, oracle)
+            mine = verify_against_golden(handle, args.config, lo, hi, oracle, kh=sc.download() if sc is not None and sc.slab else None)
         tot = exchange.allreduce([mine, 1.0], "sum") if exchange is not None else np.array([mine, 1.0])
         verified = {"rows_checked": int(tot[0]), "ranks_seen": int(tot[1])}
 
@@ -439,6 +448,10 @@ def main():
         achieved = algo_bytes / knn_avg_s / 1e9
         traffic, traffic_source = measured_traffic(nq, k)
         par = f"point-index-range shards x{world}"
+        if sc is not None and sc.slab:
+            par = (f"each rank HOLDS an index range and ANSWERS one of {world} slabs of equal population along the cloud's longest axis "
+                   "(pct_set_query_slab: the cloud is in no spatial order); the rows return to their holders as (index, K, H) records, "
+                   "12 B/point, in a second exchange per step")
         issued = None
         if dist_mode:
             issued = handle.comm_counters()
@@ -469,6 +482,7 @@ def main():
                                    + f", k={k}" + (f", eps={eps}" if eps else "") + ", grid k-NN + fused plane-align/quadric-fit/curvature "
                                    f"({cfg['base']})",
                        "points_total": n_total, "k": k, "parallelism": par,
+                       **({"ownership": "slab" if sc.slab else "range"} if sc is not None else {}),
                        **({"collectives_issued": issued} if issued is not None else {})},
             "roofline": {"bound": "hbm", "kernel": "k_knn_pair, no distance table (the fused step's sweep)", "achieved": achieved,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,

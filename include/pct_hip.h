@@ -101,6 +101,26 @@ int pct_set_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n);
 int pct_use_points_device_f32(pct_ctx* ctx, const void* dev_xyz, int64_t n);
 /* Queries owned by this handle: global index range [begin, end).  Default all. */
 int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end);
+/* Ownership by SLAB instead of by index range (multi-GPU, clouds whose row order is not a spatial order: the
+ * neighbourhood of a random index range is the whole cloud, so every rank would bin every point).  The gathered cloud
+ * is cut into `parts` slabs of equal population along its longest axis -- from a 4096-bin histogram that every rank
+ * computes alike, with the same arithmetic on the same bytes -- and this handle answers the points of slab `part`:
+ * its cell list holds that slab and a margin (checked per query like an index range's box, pct_timings.limit_retries).
+ * pct_curvature only (float32 clouds of >= 4096 points, one cell list: PCT_KNN_AUTO / PCT_KNN_GRID; k > 127 goes
+ * through the exact sweep); the rows come back as records, not by index:
+ *   pct_slab_counts    points per slab of the last pct_curvature (what every rank will send)
+ *   pct_slab_records   (public index as int32 bits, K, H) x rows of this slab -> a DEVICE buffer of 3 floats per row
+ *   pct_scatter_records   gathered records (device) -> K, H of the public rows [begin, end) (device); fails unless
+ *                         exactly end - begin records fell into the range (the slabs of the ranks partition the cloud)
+ * parts = 1 is the same path with the whole cloud as its one slab (a world of one rank); pct_set_query_range, a new
+ * cloud or parts <= 0 return the handle to index ranges.  pct_get_fit / pct_get_neighbors and
+ * the other by-index getters refuse while slab ownership is on. */
+#define PCT_SLAB_PARTS_MAX 64
+int pct_set_query_slab(pct_ctx* ctx, int32_t part, int32_t parts);
+int pct_slab_counts(pct_ctx* ctx, int64_t* counts, int32_t parts);
+int pct_slab_records(pct_ctx* ctx, float* dev_records, int64_t capacity_rows, int64_t* rows);
+int pct_scatter_records(pct_ctx* ctx, const float* dev_records, int64_t n_records, int64_t begin, int64_t end,
+                        float* dev_K, float* dev_H);
 /* Cell-occupancy target of the grid search as a multiple of (k+1); <= 0 keeps
  * the default. */
 int pct_set_grid_param(pct_ctx* ctx, double occupancy_factor);

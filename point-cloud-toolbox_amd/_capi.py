@@ -64,6 +64,10 @@ SIGNATURES = {
     "pct_set_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
     "pct_use_points_device_f32": (C.c_int, [_p, _p, C.c_int64]),
     "pct_set_query_range": (C.c_int, [_p, C.c_int64, C.c_int64]),
+    "pct_set_query_slab": (C.c_int, [_p, C.c_int32, C.c_int32]),
+    "pct_slab_counts": (C.c_int, [_p, C.POINTER(C.c_int64), C.c_int32]),
+    "pct_slab_records": (C.c_int, [_p, _p, C.c_int64, C.POINTER(C.c_int64)]),
+    "pct_scatter_records": (C.c_int, [_p, _p, C.c_int64, C.c_int64, C.c_int64, _p, _p]),
     "pct_set_grid_param": (C.c_int, [_p, C.c_double]),
     "pct_set_stats": (C.c_int, [_p, C.c_int32]),
     "pct_knn": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
@@ -303,6 +307,25 @@ class Handle:
 
     def set_query_range(self, begin, end):
         self._check(self._lib.pct_set_query_range(self._h, int(begin), int(end)))
+
+    # -- ownership by slab (multi-GPU, clouds in no spatial order; include/pct_hip.h) --------------------------------
+    def set_query_slab(self, part, parts):
+        self._check(self._lib.pct_set_query_slab(self._h, int(part), int(parts)))
+
+    def slab_counts(self, parts):
+        out = (C.c_int64 * int(parts))()
+        self._check(self._lib.pct_slab_counts(self._h, out, int(parts)))
+        return [int(v) for v in out]
+
+    def slab_records(self, dev_ptr, capacity_rows):
+        """(public index bits, K, H) of this slab's rows into the device buffer; returns the row count."""
+        rows = C.c_int64(0)
+        self._check(self._lib.pct_slab_records(self._h, _p(int(dev_ptr)), int(capacity_rows), C.byref(rows)))
+        return rows.value
+
+    def scatter_records(self, dev_records, n_records, begin, end, dev_K, dev_H):
+        self._check(self._lib.pct_scatter_records(self._h, _p(int(dev_records)), int(n_records), int(begin), int(end),
+                                                  _p(int(dev_K)), _p(int(dev_H))))
 
     def set_stats(self, enable=True):
         self._check(self._lib.pct_set_stats(self._h, int(bool(enable))))

@@ -204,6 +204,8 @@ static int new_cloud(pct_ctx* ctx, int64_t n) {
     ctx->n = n;
     ctx->q_begin = 0;
     ctx->q_end = n;
+    ctx->slab_parts = ctx->slab_part = 0;
+    ctx->slab_split_valid = false;
     ctx->grid_valid = ctx->knn_valid = ctx->fit_valid = ctx->pts4_valid = ctx->qpts4_valid = false;
     ctx->has_f64 = false;
     ctx->no_cull = ctx->culled = false;
@@ -271,9 +273,109 @@ int pct_set_query_range(pct_ctx* ctx, int64_t begin, int64_t end) {
     if (begin < 0 || end > ctx->n || begin > end) return pct_fail(ctx, PCT_ERR_INVALID, "bad query range [%lld,%lld)", (long long)begin, (long long)end);
     ctx->q_begin = begin;
     ctx->q_end = end;
+    ctx->slab_parts = ctx->slab_part = 0;
+    ctx->slab_split_valid = false;
     ctx->knn_valid = ctx->fit_valid = ctx->grid_valid = false;   // the cell order depends on the owned range
     ctx->no_cull = false;
     ctx->retries = 0;
+    return PCT_OK;
+}
+
+int pct_set_query_slab(pct_ctx* ctx, int32_t part, int32_t parts) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->n <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
+    if (parts > PCT_SLAB_PARTS_MAX || (parts >= 1 && (part < 0 || part >= parts)))
+        return pct_fail(ctx, PCT_ERR_INVALID, "bad slab %d of %d (at most %d parts)", part, parts, PCT_SLAB_PARTS_MAX);
+    if (parts >= 1 && (ctx->has_f64 || ctx->n < 4096))
+        return pct_fail(ctx, PCT_ERR_INVALID, "slab ownership serves float32 clouds of at least 4096 points (use index ranges)");
+    ctx->q_begin = 0;
+    ctx->q_end = ctx->n;                 // until the build has cut the cloud
+    ctx->slab_parts = parts >= 1 ? parts : 0;     // (one part: the whole cloud as one slab -- the same code path, for a world of one rank)
+    ctx->slab_part = parts >= 1 ? part : 0;
+    ctx->slab_split_valid = false;
+    ctx->knn_valid = ctx->fit_valid = ctx->grid_valid = false;
+    ctx->no_cull = false;
+    ctx->retries = 0;
+    return PCT_OK;
+}
+
+// by-index getters have no meaning while the rows are those of a slab
+static int refuse_in_slab_mode(pct_ctx* ctx, const char* what) {
+    if (ctx->slab_parts >= 1)
+        return pct_fail(ctx, PCT_ERR_INVALID, "%s: this handle owns a slab, not an index range (pct_slab_records / pct_scatter_records)", what);
+    return PCT_OK;
+}
+
+int pct_slab_counts(pct_ctx* ctx, int64_t* counts, int32_t parts) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->slab_parts < 1 || !ctx->slab_split_valid || !ctx->fit_valid)
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_slab_counts: no slab pass on this handle (pct_set_query_slab, pct_curvature)");
+    if (!counts || parts != ctx->slab_parts) return pct_fail(ctx, PCT_ERR_INVALID, "pct_slab_counts: %d parts asked, the cloud was cut into %d", parts, ctx->slab_parts);
+    for (int p = 0; p < parts; ++p) counts[p] = ctx->slab_counts[p];
+    return PCT_OK;
+}
+
+namespace {
+// rows of the slab in table (cell) order -> (public index, K, H)
+__global__ __launch_bounds__(256) void k_slab_records(const float4* __restrict__ sorted4, const int* __restrict__ owned_pos,
+                                                      const float* __restrict__ K, const float* __restrict__ H, int64_t rows,
+                                                      float* __restrict__ out) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    out[3 * r + 0] = sorted4[owned_pos[r]].w;          // (the public index as int32 bits)
+    out[3 * r + 1] = K[r];
+    out[3 * r + 2] = H[r];
+}
+
+__global__ __launch_bounds__(256) void k_scatter_records(const float* __restrict__ rec, int64_t n_rec, int64_t begin, int64_t end,
+                                                         float* __restrict__ K, float* __restrict__ H, unsigned long long* __restrict__ hits) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    bool hit = false;
+    if (i < n_rec) {
+        const int64_t pub = (int64_t)__float_as_int(rec[3 * i + 0]);
+        hit = pub >= begin && pub < end;
+        if (hit) {
+            K[pub - begin] = rec[3 * i + 1];
+            H[pub - begin] = rec[3 * i + 2];
+        }
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(hits, (unsigned long long)__popcll(m));
+}
+}  // namespace
+
+int pct_slab_records(pct_ctx* ctx, float* dev_records, int64_t capacity_rows, int64_t* rows_out) {
+    PCT_TRY(begin_call(ctx));
+    if (ctx->slab_parts < 1 || !ctx->slab_split_valid || !ctx->fit_valid || !ctx->knn_sorted_space || !ctx->fit_row_order)
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_slab_records: no slab pass on this handle (pct_set_query_slab, pct_curvature)");
+    const int64_t rows = ctx->q_end - ctx->q_begin;
+    if (rows_out) *rows_out = rows;
+    if (rows > capacity_rows || (rows > 0 && !dev_records))
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_slab_records: %lld rows, room for %lld", (long long)rows, (long long)capacity_rows);
+    if (rows == 0) return PCT_OK;
+    PCT_LAUNCH(k_slab_records, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, ctx->stream, (const float4*)ctx->sorted4.p,
+               (const int*)ctx->owned_pos.p, (const float*)ctx->K.p, (const float*)ctx->H.p, rows, dev_records);
+    PCT_HIP(ctx, hipGetLastError());
+    return PCT_OK;
+}
+
+int pct_scatter_records(pct_ctx* ctx, const float* dev_records, int64_t n_records, int64_t begin, int64_t end, float* dev_K, float* dev_H) {
+    PCT_TRY(begin_call(ctx));
+    if (n_records < 0 || begin < 0 || end < begin || (n_records > 0 && !dev_records) || (end > begin && (!dev_K || !dev_H)))
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_scatter_records: bad arguments");
+    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64 * sizeof(unsigned long long)));
+    unsigned long long* d_hits = (unsigned long long*)ctx->counters.p + 32;
+    PCT_HIP(ctx, hipMemsetAsync(d_hits, 0, sizeof(unsigned long long), ctx->stream));
+    if (n_records > 0)
+        PCT_LAUNCH(k_scatter_records, dim3((unsigned)((n_records + 255) / 256)), dim3(256), 0, ctx->stream, dev_records, n_records, begin,
+                   end, dev_K, dev_H, d_hits);
+    PCT_HIP(ctx, hipGetLastError());
+    unsigned long long* h = (unsigned long long*)(ctx->pin + 176);
+    PCT_HIP(ctx, hipMemcpyAsync(h, d_hits, sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if ((int64_t)*h != end - begin)
+        return pct_fail(ctx, PCT_ERR_INVALID, "pct_scatter_records: %llu of the %lld records fall into rows [%lld,%lld) -- the slabs do not partition the cloud",
+                        *h, (long long)n_records, (long long)begin, (long long)end);
     return PCT_OK;
 }
 
@@ -308,6 +410,11 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
     }
     if (algo != PCT_KNN_GRID && algo != PCT_KNN_BRUTE && algo != PCT_KNN_GRID_EXACT && algo != PCT_KNN_GRID_LEVELS && algo != PCT_KNN_TREE)
         return pct_fail(ctx, PCT_ERR_INVALID, "unknown algorithm %d", algo);
+    if (ctx->slab_parts >= 1) {            // one cell list over the slab and its margin (include/pct_hip.h)
+        if (!fuse_fit || (algo != PCT_KNN_GRID && algo != PCT_KNN_GRID_EXACT))
+            return pct_fail(ctx, PCT_ERR_INVALID, "slab ownership: pct_curvature with PCT_KNN_AUTO / PCT_KNN_GRID only");
+        auto_req = false;
+    }
     ctx->knn_valid = ctx->fit_valid = false;
     ctx->k = k;
     ctx->eps = eps;
@@ -474,6 +581,7 @@ int pct_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
 
 int pct_fit(pct_ctx* ctx) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_fit"));
     if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "plant the neighbour table first (pct_knn)");
     PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
     PCT_TRY(pct_launch_fit_table(ctx));
@@ -512,6 +620,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
 
 int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_t* idx, float* dist, int32_t* count) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_get_neighbors"));
     if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "no neighbour table");
     if (begin < ctx->q_begin || end > ctx->q_end || begin > end)
         return pct_fail(ctx, PCT_ERR_INVALID, "rows [%lld,%lld) outside the owned range [%lld,%lld)", (long long)begin,
@@ -536,6 +645,7 @@ int pct_get_neighbors(pct_ctx* ctx, int64_t begin, int64_t end, int32_t* idx, fl
 
 int pct_get_neighbor_rows(pct_ctx* ctx, const int64_t* rows, int64_t n_rows, int32_t* idx, float* dist, int32_t* count) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_get_neighbor_rows"));
     if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "no neighbour table");
     if (!rows || n_rows <= 0) return pct_fail(ctx, PCT_ERR_INVALID, "bad row list");
     for (int64_t i = 0; i < n_rows; ++i)
@@ -640,6 +750,7 @@ int pct_fit_indices_f64(pct_ctx* ctx, const int32_t* idx, const int32_t* count, 
 
 int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, double eps, int32_t* idx, double* dist) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_query_points"));
     if (ctx->n <= 0 || !ctx->xyz_view) return pct_fail(ctx, PCT_ERR_INVALID, "no cloud loaded");
     if (m < 0 || (m > 0 && (!q_xyz || !idx || !dist))) return pct_fail(ctx, PCT_ERR_INVALID, "bad query arrays");
     if (k < 1 || k > 128) return pct_fail(ctx, PCT_ERR_INVALID, "k=%d outside [1,128]", k);
@@ -660,6 +771,7 @@ int pct_query_points(pct_ctx* ctx, const double* q_xyz, int64_t m, int32_t k, do
 
 int pct_get_fit(pct_ctx* ctx, int64_t begin, int64_t end, float* coefs, float* K, float* H, float* H2) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_get_fit"));
     if (!ctx->fit_valid) return pct_fail(ctx, PCT_ERR_INVALID, "no fit results");
     const int64_t base = ctx->fit_cloud_aligned ? ctx->q_begin : 0;   // cloud-aligned vs row-aligned results
     if (begin < base || end > base + ctx->fit_rows || begin > end)
@@ -741,6 +853,7 @@ int pct_fit_quadric(pct_ctx* ctx, const float* pts, int64_t batch, int32_t m, fl
 int pct_neighbor_study_curvatures(pct_ctx* ctx, const int64_t* sample_rows, int64_t n_samples, int32_t n_lo, int32_t n_hi,
                                    float* K_out) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_neighbor_study_curvatures"));
     if (!ctx->knn_valid) return pct_fail(ctx, PCT_ERR_NO_NEIGHBORS, "plant the neighbour table first (pct_knn)");
     if (!sample_rows || !K_out || n_samples <= 0 || n_lo < 1 || n_hi < n_lo) return pct_fail(ctx, PCT_ERR_INVALID, "bad study arguments");
     if (n_hi > ctx->k) return pct_fail(ctx, PCT_ERR_INVALID, "the study needs %d neighbours per point, the table holds %d", n_hi, ctx->k);
@@ -841,6 +954,7 @@ int pct_voxel_downsample_f32(pct_ctx* ctx, const float* xyz, int64_t n, double v
 
 int pct_surface_variation(pct_ctx* ctx, int32_t k_total, float* out) {
     PCT_TRY(begin_call(ctx));
+    PCT_TRY(refuse_in_slab_mode(ctx, "pct_surface_variation"));
     if (!out || k_total < 2) return pct_fail(ctx, PCT_ERR_INVALID, "bad surface-variation arguments");
     const int64_t rows = ctx->q_end - ctx->q_begin;
     for (int attempt = 0; attempt < 2; ++attempt) {

@@ -235,11 +235,72 @@ __global__ __launch_bounds__(kBlock) void k_box_stats(const float4* __restrict__
 // others behind them in whatever order the blocks arrive (one counter increment per 4096-row chunk).
 constexpr int kCullChunk = kBlock * 16;
 
+// Ownership by slab (pct_set_query_slab): bin of a coordinate along the cut axis.  Every rank evaluates this very
+// expression on the same bytes (the library is built with -ffp-contract=off), in the histogram and in the pack alike.
+constexpr int kSlabBins = 4096;
+struct SlabCut { int axis, bin_lo, bin_hi; float x0, inv; };
+__device__ __forceinline__ int slab_bin(float x, float x0, float inv) {
+    const int b = (int)((x - x0) * inv);
+    return min(max(b, 0), kSlabBins - 1);
+}
+
+__global__ __launch_bounds__(kBlock) void k_slab_hist(const float* __restrict__ xyz, int64_t n, int axis, float x0, float inv,
+                                                      unsigned* __restrict__ hist) {
+    __shared__ unsigned s_h[kSlabBins];
+    for (int i = threadIdx.x; i < kSlabBins; i += kBlock) s_h[i] = 0;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
+        atomicAdd(&s_h[slab_bin(xyz[3 * i + axis], x0, inv)], 1u);
+    __syncthreads();
+    for (int i = threadIdx.x; i < kSlabBins; i += kBlock)
+        if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
+}
+
+// cuts: part p owns the bins [cut[p], cut[p+1]) where cut[p] = the first bin with floor(p n / parts) points below it
+__global__ __launch_bounds__(kBlock) void k_slab_cut(const unsigned* __restrict__ hist, long long n, int parts, int* __restrict__ cut,
+                                                     long long* __restrict__ counts) {
+    __shared__ long long s_cum[kSlabBins + 1];
+    __shared__ long long s_part[kBlock];
+    __shared__ int s_cut[PCT_SLAB_PARTS_MAX + 1];
+    constexpr int per = kSlabBins / kBlock;
+    long long mine = 0;
+    for (int j = 0; j < per; ++j) mine += hist[threadIdx.x * per + j];
+    s_part[threadIdx.x] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long run = 0;
+        for (int t = 0; t < kBlock; ++t) { const long long c = s_part[t]; s_part[t] = run; run += c; }
+    }
+    __syncthreads();
+    long long run = s_part[threadIdx.x];
+    for (int j = 0; j < per; ++j) { s_cum[threadIdx.x * per + j] = run; run += hist[threadIdx.x * per + j]; }
+    if (threadIdx.x == kBlock - 1) s_cum[kSlabBins] = run;
+    __syncthreads();
+    if ((int)threadIdx.x <= parts) {
+        const int p = threadIdx.x;
+        int b = kSlabBins;
+        if (p < parts) {
+            const long long want = (long long)p * n / parts;
+            int lo = 0, hi = kSlabBins;                // smallest b with cum[b] >= want (cum is non-decreasing)
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_cum[mid] >= want) hi = mid; else lo = mid + 1; }
+            b = lo;
+        }
+        s_cut[p] = b;
+        cut[p] = b;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < parts) counts[threadIdx.x] = s_cum[s_cut[threadIdx.x + 1]] - s_cum[s_cut[threadIdx.x]];
+}
+
+// SLAB: the owned points are those of the slab (compacted to the front through a second counter, in whatever order the
+// blocks arrive: the public index rides in w); otherwise the rows [q_begin, q_end), in their own order.
+template <bool SLAB>
 __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ xyz, int64_t n, Box3 box, int64_t q_begin,
-                                                      int64_t q_end, float4* __restrict__ pts4, unsigned* __restrict__ kept_others,
+                                                      int64_t q_end, SlabCut cut, float4* __restrict__ pts4, unsigned* __restrict__ kept_others,
                                                       PackRed* __restrict__ red, PackRed* __restrict__ parts) {
     __shared__ int s_cnt[16][kBlock / 64];
-    __shared__ int s_base;
+    __shared__ int s_own[16][kBlock / 64];
+    __shared__ int s_base, s_own_base;
     const float sh[3] = {0.f, 0.f, 0.f};
     PackAcc acc;
     acc.init();
@@ -247,17 +308,21 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t n_owned = q_end - q_begin;
     float px[16], py[16], pz[16];
-    unsigned keep_bits = 0;
+    unsigned keep_bits = 0, own_bits = 0;
     int bad = 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t i = base + r * kBlock + threadIdx.x;
         px[r] = py[r] = pz[r] = 0.f;
-        bool keep = false;
+        bool keep = false, own = false;
         if (i < n) {
             px[r] = xyz[3 * i + 0]; py[r] = xyz[3 * i + 1]; pz[r] = xyz[3 * i + 2];
             bad |= !(isfinite(px[r]) && isfinite(py[r]) && isfinite(pz[r]));
-            if (i >= q_begin && i < q_end) {
+            if (SLAB) {
+                const int b = slab_bin(cut.axis == 0 ? px[r] : cut.axis == 1 ? py[r] : pz[r], cut.x0, cut.inv);
+                own = b >= cut.bin_lo && b < cut.bin_hi;
+                keep = !own && in_box(box, px[r], py[r], pz[r]);
+            } else if (i >= q_begin && i < q_end) {
                 pts4[i - q_begin] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
                 acc.add(px[r], py[r], pz[r], sh);
             } else {
@@ -267,6 +332,11 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
         keep_bits |= keep ? 1u << r : 0u;
         const unsigned long long m = __ballot(keep);
         if (lane == 0) s_cnt[r][w] = (int)__popcll(m);
+        if (SLAB) {
+            own_bits |= own ? 1u << r : 0u;
+            const unsigned long long mo = __ballot(own);
+            if (lane == 0) s_own[r][w] = (int)__popcll(mo);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) {            // exclusive prefix over (round, wave), one counter increment per chunk
@@ -275,17 +345,32 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
             for (int v = 0; v < kBlock / 64; ++v) { const int c = s_cnt[r][v]; s_cnt[r][v] = total; total += c; }
         s_base = total ? (int)atomicAdd(kept_others, (unsigned)total) : 0;
     }
+    if (SLAB && threadIdx.x == 64) {
+        int total = 0;
+        for (int r = 0; r < 16; ++r)
+            for (int v = 0; v < kBlock / 64; ++v) { const int c = s_own[r][v]; s_own[r][v] = total; total += c; }
+        s_own_base = total ? (int)atomicAdd(kept_others + 1, (unsigned)total) : 0;
+    }
     __syncthreads();
     const int64_t out0 = n_owned + s_base;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const bool keep = (keep_bits >> r) & 1u;
         const unsigned long long m = __ballot(keep);
+        const int64_t i = base + r * kBlock + threadIdx.x;
         if (keep) {
-            const int64_t i = base + r * kBlock + threadIdx.x;
             const int64_t at = out0 + s_cnt[r][w] + (int)__popcll(m & ((1ull << lane) - 1ull));
-            pts4[at] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
+            if (!SLAB || at < n) pts4[at] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
             acc.add(px[r], py[r], pz[r], sh);
+        }
+        if (SLAB) {
+            const bool own = (own_bits >> r) & 1u;
+            const unsigned long long mo = __ballot(own);
+            if (own) {
+                const int64_t at = (int64_t)s_own_base + s_own[r][w] + (int)__popcll(mo & ((1ull << lane) - 1ull));
+                if (at < n_owned) pts4[at] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));   // (guard: a cut that no longer fits the buffer is reported by the host)
+                acc.add(px[r], py[r], pz[r], sh);
+            }
         }
     }
     if (__any(bad) && lane == 0) atomicOr(&red->bad, 1);
@@ -628,9 +713,73 @@ int pct_pack_points(pct_ctx* ctx, float* bbox /*6*/) {
 
 // Sharded handle: pack only the points inside the owned rows' bounding box grown by `margin_cells` first-guess
 // cell edges.  *kept_box receives the box that was applied (its faces become pct_grid::lim_*).
+// Ownership by slab: bounding box of the whole cloud, histogram along its longest axis, the cuts of all parts (on the
+// device; the cuts and the populations come back through pinned memory).  Leaves q_begin = 0, q_end = population of
+// this handle's slab: the owned points will lead the packed array.
+static int slab_split(pct_ctx* ctx) {
+    const int64_t n = ctx->n;
+    const int parts = ctx->slab_parts;
+    const int nb = grid_1d(n, kBlock * 4, 512);
+    PackRed red;
+    float ob[6];
+    PCT_TRY(red_reset(ctx, nb));
+    PCT_LAUNCH(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, (int64_t)0, n, red_parts(ctx));
+    PCT_HIP(ctx, hipGetLastError());
+    PCT_TRY(red_read(ctx, nb, &red, ob));
+    if (red.bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    int axis = 0;
+    for (int a = 1; a < 3; ++a)
+        if (ob[3 + a] - ob[a] > ob[3 + axis] - ob[axis]) axis = a;
+    const double ext = (double)ob[3 + axis] - ob[axis];
+    ctx->slab_axis = axis;
+    ctx->slab_x0 = ob[axis];
+    ctx->slab_inv = ext > 0 && isfinite((float)(kSlabBins / ext)) ? (float)(kSlabBins / ext) : 0.f;
+    for (int a = 0; a < 6; ++a) ctx->slab_bbox[a] = ob[a];
+    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 256 + kSlabBins * sizeof(unsigned)));
+    unsigned* hist = (unsigned*)((char*)ctx->scan_tmp.p + 256);
+    PCT_HIP(ctx, hipMemsetAsync(hist, 0, kSlabBins * sizeof(unsigned), ctx->stream));
+    PCT_LAUNCH(k_slab_hist, dim3(grid_1d(n, kBlock * 8, 1024)), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, axis, ctx->slab_x0,
+               ctx->slab_inv, hist);
+    int* h_cut = (int*)(ctx->pin + 2560);                       // mapped pinned memory: the kernel writes the host's copy
+    long long* h_counts = (long long*)(ctx->pin + 3072);
+    PCT_LAUNCH(k_slab_cut, dim3(1), dim3(kBlock), 0, ctx->stream, (const unsigned*)hist, (long long)n, parts, h_cut, h_counts);
+    PCT_HIP(ctx, hipGetLastError());
+    PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    long long total = 0;
+    for (int p = 0; p < parts; ++p) { ctx->slab_counts[p] = h_counts[p]; total += h_counts[p]; }
+    if (total != n || h_cut[0] != 0 || h_cut[parts] != kSlabBins)
+        return pct_fail(ctx, PCT_ERR_INVALID, "slab cut: %lld of %lld points in %d parts", total, (long long)n, parts);
+    ctx->slab_bin_lo = h_cut[ctx->slab_part];
+    ctx->slab_bin_hi = h_cut[ctx->slab_part + 1];
+    ctx->q_begin = 0;
+    ctx->q_end = ctx->slab_counts[ctx->slab_part];
+    ctx->slab_split_valid = true;
+    return PCT_OK;
+}
+
 static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* red, Box3* kept_box) {
     const int64_t n = ctx->n, n_owned = ctx->q_end - ctx->q_begin;
+    const bool slab = ctx->slab_parts >= 1;
     Box3 box;
+    if (slab) {
+        // the slab and 4 first-guess cell edges either side of it along the cut axis, everything across; the outer
+        // faces of the first and the last slab are open.  After a limit retry (no_cull): every point.
+        const float* ob = ctx->slab_bbox;
+        const double ex = (double)ob[3] - ob[0], ey = (double)ob[4] - ob[1], ez = (double)ob[5] - ob[2];
+        const double emax = fmax(ex, fmax(ey, ez));
+        double area = 1.2 * (ex * ey + ey * ez + ex * ez);
+        if (!(area > 0)) area = emax * emax;
+        double a0 = sqrt(target * area / (double)n);
+        if (!(a0 > 0) || !isfinite(a0)) a0 = emax;
+        double margin = 4.0 * a0;
+        if (const char* e = pct_getenv("PCT_SLAB_MARGIN")) margin = atof(e) * a0;      // test aid: a thin margin forces the limit retry
+        for (int a = 0; a < 3; ++a) { box.lo[a] = -INFINITY; box.hi[a] = INFINITY; }
+        if (!ctx->no_cull && ctx->slab_inv > 0) {
+            const int ax = ctx->slab_axis;
+            if (ctx->slab_bin_lo > 0) box.lo[ax] = (float)((double)ctx->slab_x0 + (double)ctx->slab_bin_lo / ctx->slab_inv - margin);
+            if (ctx->slab_bin_hi < kSlabBins) box.hi[ax] = (float)((double)ctx->slab_x0 + (double)ctx->slab_bin_hi / ctx->slab_inv + margin);
+        }
+    } else {
     // A handle that is fed a stream of similar clouds (same size, same owned range) reuses the box of the last call
     // instead of measuring the owned rows first (one pass and one host synchronisation less).  A stale box is safe:
     // the owned rows are packed whatever it says, and a query that reaches past a face makes the sweep repeat
@@ -664,19 +813,28 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
         ctx->cull_box_q0 = ctx->q_begin;
         ctx->cull_box_q1 = ctx->q_end;
     }
+    }
     *kept_box = box;
 
     const int nchunk = (int)((n + kCullChunk - 1) / kCullChunk);
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));           // worst case: everything is kept
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 64));
     PCT_TRY(red_reset(ctx, nchunk));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, sizeof(unsigned), ctx->stream));
-    PCT_LAUNCH(k_cull_pack, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end,
-                       (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, 2 * sizeof(unsigned), ctx->stream));
+    const SlabCut cut = {ctx->slab_axis, ctx->slab_bin_lo, ctx->slab_bin_hi, ctx->slab_x0, ctx->slab_inv};
+    if (slab)
+        PCT_LAUNCH(k_cull_pack<true>, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end, cut,
+                   (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
+    else
+        PCT_LAUNCH(k_cull_pack<false>, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end, cut,
+                   (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     PCT_TRY(red_read(ctx, nchunk, red, bbox));
     if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
+    if (slab && (int64_t)((const unsigned*)(ctx->pin + 160))[1] != n_owned)
+        return pct_fail(ctx, PCT_ERR_INVALID, "slab pack found %u owned points, the cut said %lld (was the cloud's buffer written meanwhile?)",
+                        ((const unsigned*)(ctx->pin + 160))[1], (long long)n_owned);
     const int64_t kept = n_owned + (int64_t)*(const unsigned*)(ctx->pin + 160);
     if ((int64_t)red->cnt != kept || kept > n)
         return pct_fail(ctx, PCT_ERR_INVALID, "cull pass kept %lld / counted %lld points", (long long)red->cnt, (long long)kept);
@@ -780,13 +938,17 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
     if (ctx->level_mode) cell_cap = (int64_t)1 << 24;
     else if (32 * ctx->n > cell_cap) cell_cap = 32 * ctx->n < ((int64_t)1 << 30) ? 32 * ctx->n : (int64_t)1 << 30;
     const float* own_flag = (const float*)ctx->own_flag;   // level passes: ownership by wanted-edge band
+    const bool slab = ctx->slab_parts >= 1 && !own_flag;
+    if (slab) PCT_TRY(slab_split(ctx));                    // (sets the owned count: q_begin = 0, q_end = this slab's population)
     const int64_t n_owned = own_flag ? ctx->own_count : ctx->q_end - ctx->q_begin;
-    const bool sharded = own_flag || ctx->q_begin > 0 || ctx->q_end < ctx->n;   // some points are candidates only
+    const bool sharded = own_flag || ctx->q_begin > 0 || ctx->q_end < ctx->n || slab;   // some points are candidates only
 
     float bbox[6];
     PackRed red;
     Box3 kept_box = {};
-    const bool try_cull = !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !pct_getenv("PCT_NO_CULL");
+    // (a slab's owned points are found by the pack itself: it always runs, with an open box after a limit retry)
+    const bool try_cull = slab ? n_owned > 0
+                               : !own_flag && sharded && n_owned > 0 && !ctx->has_f64 && !ctx->no_cull && !pct_getenv("PCT_NO_CULL");
     ctx->tm.grid_iters = 0;
     // Speculation: a handle fed a stream of similar clouds builds the cell list over the (trimmed) box of the previous
     // call without waiting for the new bounding box -- any box is a valid grid box, points outside are clamped into

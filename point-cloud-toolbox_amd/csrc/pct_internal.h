@@ -68,6 +68,15 @@ struct pct_ctx {
     bool cull_box_valid = false;
     int64_t cull_box_n = 0, cull_box_q0 = 0, cull_box_q1 = 0;
     int32_t retries = 0;
+    // Ownership by slab (pct_set_query_slab): the cloud is cut into slab_parts slabs of equal population along its
+    // longest axis and this handle answers the points of slab_part.  The cut comes from a 4096-bin histogram every
+    // rank computes alike from the gathered cloud; q_begin / q_end then refer to the PACKED array (owned first).
+    int32_t slab_part = 0, slab_parts = 0;
+    int32_t slab_axis = 0, slab_bin_lo = 0, slab_bin_hi = 0;
+    float slab_x0 = 0, slab_inv = 0;
+    float slab_bbox[6] = {0, 0, 0, 0, 0, 0};
+    int64_t slab_counts[PCT_SLAB_PARTS_MAX] = {};
+    bool slab_split_valid = false;
     double hint_edge = 0, hint_guess = 0, hint_target = 0;   // warm start of the cell-size search (pct_build_grid)
     float spec_bbox[6] = {0, 0, 0, 0, 0, 0};   // grid box of the last plain build (trimmed), reused speculatively
     float spec_raw[6] = {0, 0, 0, 0, 0, 0};    // raw bounding box of that cloud

@@ -147,6 +147,20 @@ def rendezvous_unique_id(rank, world, make_id, addr=None, port=None, timeout=180
     raise TimeoutError(f"rendezvous: rank {rank} could not reach {addr}:{ports[0]}..{ports[-1]}: {last}")
 
 
+def scatter_records_host(records, lo, hi):
+    """(index bits, K, H) records of every rank -> K, H of rows [lo, hi); the records must cover the range exactly once
+    (what ``pct_scatter_records`` checks on the device)."""
+    records = np.asarray(records, np.float32).reshape(-1, 3)
+    idx = np.ascontiguousarray(records[:, 0]).view(np.int32).astype(np.int64)
+    sel = (idx >= lo) & (idx < hi)
+    if int(sel.sum()) != hi - lo or len(np.unique(idx[sel])) != hi - lo:
+        raise RuntimeError(f"{int(sel.sum())} records for the {hi - lo} rows [{lo},{hi}): the slabs do not partition the cloud")
+    K, H = np.empty(hi - lo, np.float32), np.empty(hi - lo, np.float32)
+    K[idx[sel] - lo] = records[sel, 1]
+    H[idx[sel] - lo] = records[sel, 2]
+    return K, H
+
+
 # ------------------------------------------------------------------ exchange
 class RcclExchange:
     """All-gather of device-resident float32 shards through the handle's RCCL communicator (``pct_comm_*``).
@@ -186,11 +200,25 @@ class ShardedCurvature:
     device buffers the handle allocates (``setup_device``), two gather buffers alternate so that the exchange of cloud
     i+1 overlaps the kernels of cloud i.  CPU tests inject ``exchange`` (host arrays) and ``compute`` -- a checker with
     the signature ``compute(full_points, lo, hi, k, eps) -> (K, H)``.
+
+    ``ownership``: which rows a rank ANSWERS (it always HOLDS and returns the index range [lo, hi) of the cloud).
+    ``"range"``: its own rows -- right when the row order is a spatial order (scan order, tile after tile): the points
+    near an index range are a fraction of the cloud.  ``"slab"``: the points of the rank-th of ``world`` slabs of equal
+    population along the cloud's longest axis (``pct_set_query_slab``; every rank cuts the gathered cloud alike) --
+    for clouds in no spatial order, where the neighbourhood of an index range is the whole cloud and every rank would
+    bin every point.  The rows then travel back to their holders in a second exchange: (index, K, H) records, 12 B per
+    point, all-gathered (slab populations differ by a few rows: the padded form) and scattered into [lo, hi) on the
+    device.  Injected slab checker: ``compute(full_points, rank, world, k, eps) -> (idx, K, H, counts)``.
     """
 
-    def __init__(self, n_total, k, rank, world, eps=None, handle=None, exchange=None, compute=None):
+    def __init__(self, n_total, k, rank, world, eps=None, handle=None, exchange=None, compute=None, ownership="range"):
         self.n_total, self.k, self.rank, self.world, self.eps = int(n_total), int(k), int(rank), int(world), eps
         self.handle, self.exchange, self.compute = handle, exchange, compute
+        if ownership not in ("range", "slab"):
+            raise ValueError(f"ownership must be 'range' or 'slab', not {ownership!r}")
+        self.slab = ownership == "slab" and self.n_total >= 4096      # (pct_set_query_slab's floor; every rank decides alike)
+        self._rec_send = self._rec_recv = self._kh = None
+        self._rec_cap = 0
         self.lo, self.hi = shard_range(self.n_total, rank, world)
         self.counts = np.asarray(shard_sizes(self.n_total, world), dtype=np.int64) * 3       # floats per rank
         self._send = self._bufs = None
@@ -214,7 +242,17 @@ class ShardedCurvature:
             self.run_device(self.end_exchange(self.begin_exchange(self._steps)))
             return self.download()
         full = local_pts if self.world == 1 else self.exchange.allgather_host(local_pts, self.counts)
-        return self.compute(full, self.lo, self.hi, self.k, self.eps)
+        if not self.slab:
+            return self.compute(full, self.lo, self.hi, self.k, self.eps)
+        idx, K, H, counts = self.compute(full, self.rank, self.world, self.k, self.eps)
+        if len(idx) != counts[self.rank]:
+            raise RuntimeError(f"rank {self.rank}: {len(idx)} slab rows, the cut said {counts[self.rank]}")
+        rec = np.empty((len(idx), 3), np.float32)
+        rec[:, 0] = np.asarray(idx, np.int32).view(np.float32)
+        rec[:, 1], rec[:, 2] = K, H
+        if self.world > 1:
+            rec = self.exchange.allgather_host(rec.reshape(-1), np.asarray(counts, np.int64) * 3).reshape(-1, 3)
+        return scatter_records_host(rec, self.lo, self.hi)
 
     # ---- device buffers ---------------------------------------------------------------------------------------
     def setup_device(self):
@@ -239,23 +277,61 @@ class ShardedCurvature:
         """Start the all-gather of the resident shard into gather buffer ``i % 2``; returns a ticket."""
         self.setup_device()
         if not self.collective:
-            return self._bufs[0]
-        return self.exchange.begin(self._send, self._bufs[i % 2], self.counts)
+            return [None, (self._bufs[0],)]
+        self._open = [self.exchange.begin(self._send, self._bufs[i % 2], self.counts), None]
+        return self._open
 
     def end_exchange(self, ticket):
-        if not self.collective:
-            return ticket
-        return self.exchange.end(ticket)
+        """The gathered buffer of ``ticket`` (waits for its exchange once; asking again returns the same buffer)."""
+        if ticket[1] is None:
+            ticket[1] = (self.exchange.end(ticket[0]),)
+            if getattr(self, "_open", None) is ticket:
+                self._open = None
+        return ticket[1][0]
 
     def run_device(self, full_ptr):
         """Hand the gathered device buffer to the HIP path in place (no copy): it stays untouched until the next
         exchange into it, which is ordered behind this pass on the device (pct_comm_allgather_f32)."""
         h = self.handle
         h.use_points_device(full_ptr, self.n_total)
-        h.set_query_range(self.lo, self.hi)
+        if not self.slab:
+            h.set_query_range(self.lo, self.hi)
+            h.curvature(self.k, self.eps or 0.0)
+            return
+        h.set_query_slab(self.rank, self.world)
         h.curvature(self.k, self.eps or 0.0)
+        counts = np.asarray(h.slab_counts(self.world), dtype=np.int64)
+        mine = int(counts[self.rank])
+        if self._kh is None:
+            own = max(self.hi - self.lo, 1)
+            self._kh = (h.device_alloc(own * 4), h.device_alloc(own * 4))
+            if self.collective:
+                self._rec_recv = h.device_alloc(max(self.n_total, 1) * 12)
+        if mine > self._rec_cap:                              # (equal populations: grows once, by the few rows the bins allow)
+            if self._rec_send is not None:
+                h.synchronize()
+                if self.collective:
+                    h.comm_synchronize()
+                h.device_free(self._rec_send)
+            self._rec_cap = min(self.n_total, mine + mine // 16 + 1024)
+            self._rec_send = h.device_alloc(self._rec_cap * 12)
+        h.slab_records(self._rec_send, self._rec_cap)
+        records = self._rec_send
+        if self.collective:
+            # one exchange at a time per handle: the gather of the NEXT cloud may be in flight on the exchange stream
+            # (it overlapped this pass); the records queue up behind it there
+            if getattr(self, "_open", None) is not None:
+                self.end_exchange(self._open)
+            records = self.exchange.end(self.exchange.begin(self._rec_send, self._rec_recv, counts * 3))
+        h.scatter_records(records, self.n_total, self.lo, self.hi, *self._kh)
 
     def download(self):
+        if self.slab:
+            K, H = np.empty(self.hi - self.lo, np.float32), np.empty(self.hi - self.lo, np.float32)
+            if len(K):
+                self.handle.device_download(self._kh[0], K)
+                self.handle.device_download(self._kh[1], H)
+            return K, H
         _, K, H, _ = self.handle.get_fit(self.lo, self.hi, coefs=False, H2=False)
         return K, H
 
@@ -265,6 +341,7 @@ class ShardedCurvature:
             h.synchronize()
             if self.collective:
                 h.comm_synchronize()
-            for p in [self._send] + self._bufs:
-                h.device_free(p)
+            for p in [self._send] + self._bufs + [self._rec_send, self._rec_recv] + list(self._kh or ()):
+                if p is not None:
+                    h.device_free(p)
             self._send = self._bufs = None

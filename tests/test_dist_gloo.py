@@ -90,6 +90,37 @@ class HostHandle:
     def curvature(self, k, eps):
         self.seen.append((self.cloud.copy(), self.range, k, eps))
 
+    # ownership by slab: the cut here is by rank of the x coordinate (any rule every rank applies alike will do);
+    # "K" of a point is twice its public index, "H" its negative, so that a misplaced record shows
+    def set_query_slab(self, part, parts):
+        self.range = ("slab", part, parts)
+        order = np.argsort(self.cloud[:, 0], kind="stable")
+        cuts = [len(order) * p // parts for p in range(parts + 1)]
+        self.counts = [cuts[p + 1] - cuts[p] for p in range(parts)]
+        self.mine = np.sort(order[cuts[part]:cuts[part + 1]])
+
+    def slab_counts(self, parts):
+        return list(self.counts)
+
+    def slab_records(self, buf, capacity_rows):
+        import torch
+        assert len(self.mine) <= capacity_rows
+        rec = np.empty((len(self.mine), 3), np.float32)
+        rec[:, 0] = self.mine.astype(np.int32).view(np.float32)
+        rec[:, 1], rec[:, 2] = 2.0 * self.mine, -1.0 * self.mine
+        buf[:rec.size].copy_(torch.from_numpy(rec.reshape(-1)))
+        return len(self.mine)
+
+    def scatter_records(self, records, n_records, lo, hi, K, H):
+        import torch
+        from point_cloud_toolbox_amd.dist import scatter_records_host
+        k, h = scatter_records_host(records[:3 * n_records].numpy(), lo, hi)
+        K[:hi - lo].copy_(torch.from_numpy(k))
+        H[:hi - lo].copy_(torch.from_numpy(h))
+
+    def device_download(self, buf, host):
+        host[...] = buf[:host.size].numpy().reshape(host.shape)
+
 
 def _init(rank, world, port):
     sys.path.insert(0, ROOT)
@@ -191,6 +222,100 @@ def test_double_buffered_exchange_delivers_every_cloud_intact(tmp_path):
     for i in range(steps):
         want = np.concatenate([shapes.torus_scan_order(n, world, r, seed=100 + i) for r in range(world)])
         assert np.array_equal(got[f"arr_{i}"], want), f"cloud {i}"
+
+
+def _slab_pipeline_worker(rank, world, port, n, steps, out_dir):
+    """The pipeline above with ownership by slab: after every pass the rank's records go out in a SECOND exchange --
+    queued behind the gather of the next cloud, which is in flight -- and come back scattered into its index range."""
+    dist = _init(rank, world, port)
+    from point_cloud_toolbox_amd import shapes
+    from point_cloud_toolbox_amd.dist import ShardedCurvature
+
+    h = HostHandle()
+    sc = ShardedCurvature(n, 5, rank, world, eps=0.25, handle=h, exchange=GlooExchange(rank, world), ownership="slab")
+    assert sc.slab and sc.collective
+    clouds = [shapes.torus_random(n, seed=200 + i, lo=sc.lo, hi=sc.hi) for i in range(steps + 1)]
+    sc.upload_shard(clouds[0])
+    ticket = sc.begin_exchange(0)
+    for i in range(steps):
+        cur = sc.end_exchange(ticket)
+        sc.upload_shard(clouds[i + 1])
+        ticket = sc.begin_exchange(i + 1)
+        sc.run_device(cur)                                   # ends that exchange itself before the records go out
+        K, H = sc.download()
+        rows = np.arange(sc.lo, sc.hi, dtype=np.float32)
+        assert np.array_equal(K, 2.0 * rows) and np.array_equal(H, -rows), (rank, i)
+        assert h.seen[-1][1] == ("slab", rank, world)
+    assert sc.end_exchange(ticket) is not None               # (asked twice: the same buffer, no second wait)
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "slab_pipe.npz"), *[s_[0] for s_ in h.seen])
+    dist.barrier()
+    sc.close()
+    dist.destroy_process_group()
+
+
+def test_slab_ownership_sends_the_rows_back_in_a_second_exchange(tmp_path):
+    import torch.multiprocessing as tmp_mp
+    import pointCloudToolbox  # noqa: F401
+    from point_cloud_toolbox_amd import shapes
+
+    world, n, steps, port = 2, 5001, 4, _free_port()
+    tmp_mp.spawn(_slab_pipeline_worker, args=(world, port, n, steps, str(tmp_path)), nprocs=world, join=True)
+    got = np.load(os.path.join(str(tmp_path), "slab_pipe.npz"))
+    for i in range(steps):
+        assert np.array_equal(got[f"arr_{i}"], shapes.torus_random(n, seed=200 + i)), f"cloud {i}"
+
+
+def _slab_oracle_worker(rank, world, port, n, k, out_dir):
+    dist = _init(rank, world, port)
+    from point_cloud_toolbox_amd import shapes
+    from point_cloud_toolbox_amd.dist import ShardedCurvature, shard_range
+    import pct_oracle as oracle
+
+    def compute(full, part, parts, kk, eps):                 # a slab checker: cut by the rank of the x coordinate
+        order = np.argsort(full[:, 0], kind="stable")
+        cuts = [len(order) * p // parts for p in range(parts + 1)]
+        rows = np.sort(order[cuts[part]:cuts[part + 1]])
+        r = oracle.pipeline_batched(full, kk, rows=rows, workers=1)
+        return rows, r["K"], r["H"], [cuts[p + 1] - cuts[p] for p in range(parts)]
+
+    lo, hi = shard_range(n, rank, world)
+    local = shapes.torus_random(n, seed=22, lo=lo, hi=hi)
+    sc = ShardedCurvature(n, k, rank, world, exchange=GlooExchange(rank, world), compute=compute, ownership="slab")
+    K, H = sc.step(local)
+    assert len(K) == hi - lo
+    np.savez(os.path.join(out_dir, f"slab_out_{rank}.npz"), K=K, H=H)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_slab_ownership_matches_single_process(tmp_path):
+    import torch.multiprocessing as tmp_mp
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pct_oracle as oracle
+    import pointCloudToolbox  # noqa: F401
+    from point_cloud_toolbox_amd import shapes
+
+    n, k, port = 4101, 20, _free_port()
+    tmp_mp.spawn(_slab_oracle_worker, args=(2, port, n, k, str(tmp_path)), nprocs=2, join=True)
+    parts = [np.load(tmp_path / f"slab_out_{r}.npz") for r in range(2)]
+    K, H = np.concatenate([p["K"] for p in parts]), np.concatenate([p["H"] for p in parts])
+    ref = oracle.pipeline_batched(shapes.torus_random(n, seed=22), k, workers=1)
+    assert np.array_equal(K, ref["K"]) and np.array_equal(H, ref["H"])
+
+
+def test_records_that_do_not_partition_the_rows_are_refused(built):
+    from point_cloud_toolbox_amd.dist import scatter_records_host
+    rec = np.zeros((6, 3), np.float32)
+    rec[:, 0] = np.array([4, 2, 3, 5, 0, 1], np.int32).view(np.float32)
+    rec[:, 1] = np.arange(6)
+    K, H = scatter_records_host(rec, 2, 5)
+    assert K.tolist() == [1.0, 2.0, 0.0]
+    with pytest.raises(RuntimeError, match="partition"):
+        scatter_records_host(rec[1:], 2, 5)                  # row 4 is missing
+    rec[1, 0] = rec[2, 0]
+    with pytest.raises(RuntimeError, match="partition"):
+        scatter_records_host(rec, 2, 5)                      # row 3 twice, row 2 missing
 
 
 def _rdzv_worker(rank, world, port, q):

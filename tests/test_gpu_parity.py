@@ -579,6 +579,138 @@ def test_query_range_shards_are_bit_identical(gpu):
         assert np.array_equal(np.concatenate([p[j] for p in parts]), ref)
 
 
+def _slab_pass(h, pts, k, parts, eps=0.0):
+    """Every slab of `parts` on one handle, its records appended to one device buffer (what the ranks' all-gather
+    would assemble), then scattered back into public order.  Returns K, H, per-part timings."""
+    n = len(pts)
+    rec = h.device_alloc(n * 12)
+    Kd, Hd = h.device_alloc(n * 4), h.device_alloc(n * 4)
+    off, tms = 0, []
+    try:
+        for part in range(parts):
+            h.set_query_slab(part, parts)
+            h.curvature(k, eps)
+            counts = h.slab_counts(parts)
+            assert sum(counts) == n and len(counts) == parts
+            rows = h.slab_records(rec + off * 12, n - off)
+            assert rows == counts[part]
+            t = h.timings()
+            t["rows"] = rows
+            tms.append(t)
+            off += rows
+        assert off == n
+        h.scatter_records(rec, n, 0, n, Kd, Hd)
+        K, H = np.empty(n, np.float32), np.empty(n, np.float32)
+        h.device_download(Kd, K)
+        h.device_download(Hd, H)
+        # a rank scatters its own index range out of everybody's records
+        lo, hi = n // 3, n // 3 + 1000
+        h.scatter_records(rec, n, lo, hi, Kd, Hd)
+        Ks = np.empty(hi - lo, np.float32)
+        h.device_download(Kd, Ks)
+        assert np.array_equal(Ks.view(np.uint32), K[lo:hi].view(np.uint32))
+        # records that do not cover the range are refused (here: the last slab's rows are missing)
+        if parts > 1 and tms[-1]["rows"] > 0:
+            with pytest.raises(ValueError, match="partition"):
+                h.scatter_records(rec, n - tms[-1]["rows"], 0, n, Kd, Hd)
+    finally:
+        for p_ in (rec, Kd, Hd):
+            h.device_free(p_)
+    return K, H, tms
+
+
+@pytest.mark.parametrize("parts", [1, 2, 3, 8])
+def test_slab_shards_of_an_unsorted_cloud_are_bit_identical(gpu, parts):
+    """Ownership by slab (pct_set_query_slab): a cloud in NO spatial order is cut into slabs of equal population; each
+    part's cell list holds its slab and a margin instead of the whole cloud, and K, H of every row are the bits of the
+    unsharded run."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].egg_carton_random(300_000, seed=31)
+    n, k = len(pts), 50
+    h = capi.Handle(0)
+    h.set_points(pts)
+    h.curvature(k)
+    _, K0, H0, _ = h.get_fit(0, n, coefs=False, H2=False)
+    K, H, tms = _slab_pass(h, pts, k, parts)
+    assert np.array_equal(K.view(np.uint32), K0.view(np.uint32)) and np.array_equal(H.view(np.uint32), H0.view(np.uint32))
+    for t in tms:
+        assert abs(t["rows"] - n / parts) < 0.01 * n, tms                        # equal populations (4096 bins)
+        assert t["rows"] <= t["grid_points"] <= n / parts + 0.25 * n, t          # the slab and its margin, not the cloud
+        assert t["limit_retries"] == 0
+    # by-index getters have no meaning for a slab; an index range (or a new cloud) brings them back
+    with pytest.raises(ValueError, match="slab"):
+        h.get_fit(0, 10)
+    with pytest.raises(ValueError, match="slab"):
+        h.knn(k)
+    h.set_query_range(0, n)
+    h.curvature(k)
+    _, K1, _, _ = h.get_fit(0, n, coefs=False, H2=False)
+    assert np.array_equal(K1.view(np.uint32), K0.view(np.uint32))
+    with pytest.raises(ValueError):
+        h.slab_counts(parts)
+    h.close()
+
+
+def test_slab_margin_too_thin_is_noticed_and_redone(gpu, monkeypatch):
+    """The margin either side of a slab is a guess; the sweep checks it per query and the pass is repeated with every
+    point when a neighbourhood reaches past a face -- forced here by a margin of a hundredth of a cell.  Also: eps > 0,
+    k = 80 (two list registers), k = 200 (exact sweep), a cloud whose longest axis holds ties."""
+    capi = gpu["capi"]
+    pts = gpu["shapes"].torus_random(120_000, seed=8)
+    n = len(pts)
+    h = capi.Handle(0)
+    for k, eps in ((30, 0.0), (80, 0.0), (40, 0.02), (200, 0.0)):
+        h.set_points(pts)
+        h.curvature(k, eps)
+        _, K0, H0, _ = h.get_fit(0, n, coefs=False, H2=False)
+        monkeypatch.setenv("PCT_SLAB_MARGIN", "0.01")
+        K, H, tms = _slab_pass(h, pts, k, 4, eps)
+        assert sum(t["limit_retries"] for t in tms) >= 1, tms
+        assert any(t["grid_points"] == n for t in tms)
+        monkeypatch.delenv("PCT_SLAB_MARGIN")
+        assert np.array_equal(K.view(np.uint32), K0.view(np.uint32), ) and np.array_equal(H.view(np.uint32), H0.view(np.uint32))
+        K, H, tms = _slab_pass(h, pts, k, 4, eps)
+        assert sum(t["limit_retries"] for t in tms) == 0
+        assert np.array_equal(K.view(np.uint32), K0.view(np.uint32)) and np.array_equal(H.view(np.uint32), H0.view(np.uint32))
+    # a lattice: thousands of points share each coordinate of the cut axis, whole planes fall into one bin
+    g = gpu["shapes"].egg_carton_grid(300)
+    h.set_points(g)
+    h.curvature(20)
+    _, K0, H0, _ = h.get_fit(0, len(g), coefs=False, H2=False)
+    K, H, tms = _slab_pass(h, g, 20, 7)
+    assert np.array_equal(K.view(np.uint32), K0.view(np.uint32)) and np.array_equal(H.view(np.uint32), H0.view(np.uint32))
+    # every point in one plane across the cut axis but a few: most slabs are empty
+    flat = gpu["shapes"].egg_carton_random(20_000, seed=5).copy()
+    flat[:, 0] *= 1e-3; flat[:, 1] *= 1e-3; flat[:, 2] = 0.0
+    flat[:5, 2] = np.linspace(1.0, 5.0, 5)
+    h.set_points(flat)
+    h.curvature(20, algo=capi.KNN_GRID)
+    _, K0, H0, _ = h.get_fit(0, len(flat), coefs=False, H2=False)
+    K, H, tms = _slab_pass(h, flat, 20, 4)
+    assert sorted(t["rows"] for t in tms)[:2] == [0, 0] or min(t["rows"] for t in tms) == 0, tms
+    assert np.array_equal(K.view(np.uint32), K0.view(np.uint32), ) and np.array_equal(H.view(np.uint32), H0.view(np.uint32))
+    # refused: small clouds, float64 clouds, bad parts
+    h.set_points(pts[:1000])
+    with pytest.raises(ValueError, match="4096"):
+        h.set_query_slab(0, 2)
+    h.set_points(pts.astype(np.float64))
+    with pytest.raises(ValueError):
+        h.set_query_slab(0, 2)
+    h.set_points(pts)
+    for bad in ((2, 2), (-1, 2), (0, 65)):
+        with pytest.raises(ValueError):
+            h.set_query_slab(*bad)
+    h.set_query_slab(0, 1)                    # one part: the same path, the whole cloud as its one slab
+    h.curvature(30)
+    assert h.slab_counts(1) == [n]
+    with pytest.raises(ValueError, match="slab"):
+        h.get_fit(0, 10)
+    h.set_query_slab(0, 0)                    # off: index ranges again
+    h.curvature(30)
+    h.get_fit(0, 10)
+    h.close()
+
+
 def test_scan_ordered_shards_keep_only_nearby_points(gpu):
     """A handle that owns a spatially coherent index range (scan order) packs only the points near it;
     every value stays bit-identical to the unsharded run."""
@@ -1017,7 +1149,7 @@ def test_neighbor_study_on_a_plane_converges_low(gpu):
 
 
 @pytest.mark.parametrize("config,force,issued", [("c4", "", None), ("c4", "allgather", "allgather"), ("c4", "bcast", "broadcast_groups"),
-                                                 ("c5", "padded", "padded_allgather")])
+                                                 ("c4", "padded", "padded_allgather"), ("c5", "padded", "padded_allgather")])
 def test_distributed_step_on_one_rank(gpu, tmp_path, config, force, issued):
     """The multi-GPU code path of bench.py -- RCCL communicator behind the C ABI (no PyTorch in the process), unique id
     through the TCP rendezvous, exchange into a device buffer on the exchange stream, zero-copy hand-over, owned-range
@@ -1040,12 +1172,16 @@ def test_distributed_step_on_one_rank(gpu, tmp_path, config, force, issued):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 1e7 and out["stage_ms"]["knn"] > 0 and out["scaling"] == "strong"
     assert out["verified"] == {"rows_checked": 2000, "ranks_seen": 1}
+    # C4 (egg carton, rows in no spatial order) runs with ownership by slab: cut, pack, records, second exchange, scatter
+    # -- all of it also with one rank, whose one slab is the cloud; C5 (tile after tile) keeps index ranges
+    assert out["config"]["ownership"] == ("slab" if config == "c4" else "range")
     got = out["config"]["collectives_issued"]
     if issued is None:
         assert got["allgather"] == got["padded_allgather"] == got["broadcast_groups"] == 0
         assert "no collective" in out["config"]["parallelism"]
     else:
-        assert got[issued] >= 4 and sum(got[k] for k in ("allgather", "padded_allgather", "broadcast_groups")) == got[issued]
+        per_step = 2 if config == "c4" else 1                 # slab ownership: coordinates out, records back
+        assert got[issued] >= 4 * per_step and sum(got[k] for k in ("allgather", "padded_allgather", "broadcast_groups")) == got[issued]
         assert "RCCL" in out["config"]["parallelism"]
 
 
@@ -1161,6 +1297,91 @@ def test_sharded_driver_on_four_handles_with_a_loopback_exchange(gpu):
         ref.curvature(k, 0.0, capi.KNN_GRID)
         _, K0, H0, _ = ref.get_fit(0, n, coefs=False, H2=False)
         assert np.array_equal(np.concatenate(got_K), K0) and np.array_equal(np.concatenate(got_H), H0), step
+    for d in drivers:
+        d.close()
+    for h in handles + [ref]:
+        h.close()
+
+
+def test_slab_driver_on_four_handles_with_a_loopback_exchange(gpu):
+    """The same four-rank job on a cloud in NO spatial order, ownership by slab: every rank holds an index range, cuts
+    the gathered cloud like the others, answers its slab, and gets the rows of its index range back out of everybody's
+    records -- the driver's own sequence (gather, pass, records, second exchange, scatter), one thread per rank, the
+    exchange an in-process stand-in with a barrier where the collective has one.  Two clouds, the gather of the second
+    in flight while the first is answered (bench.py's pipeline).  Bit for bit the whole-cloud handle's values."""
+    import threading
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    from point_cloud_toolbox_amd.dist import ShardedCurvature, shard_range
+    world, n, k = 4, 150_003, 30
+
+    class RankHandle(capi.Handle):
+        def comm_synchronize(self):
+            self.synchronize()
+
+    gate = threading.Barrier(world)
+
+    class Loopback:
+        def __init__(self, hub, rank):
+            self.hub, self.rank, self.serial = hub, rank, 0
+
+        def begin(self, send, recv, counts):
+            self.serial += 1
+            self.hub[(self.rank, self.serial)] = (send, recv, [int(c) for c in counts])
+            return self.serial
+
+        def end(self, serial):
+            handles[self.rank].synchronize()          # (what the send buffer holds has been written)
+            gate.wait()                               # every rank has begun this exchange
+            _, recv, counts = self.hub[(self.rank, serial)]
+            off = 0
+            for src in range(world):
+                host = np.empty(counts[src], np.float32)
+                if counts[src]:
+                    handles[self.rank].device_download(self.hub[(src, serial)][0], host)
+                    handles[self.rank].device_upload(recv + 4 * off, host)
+                off += counts[src]
+            gate.wait()                               # nobody's send buffer changes while another rank reads it
+            return recv
+
+    handles = [RankHandle(0) for _ in range(world)]
+    hub = {}
+    drivers = [ShardedCurvature(n, k, r, world, handle=handles[r], exchange=Loopback(hub, r), ownership="slab") for r in range(world)]
+    assert all(d.slab and d.collective for d in drivers)
+    clouds = [shapes.egg_carton_random(n, seed=seed) for seed in (41, 42)]
+    results, errors = {}, []
+
+    def rank_main(r):
+        try:
+            d = drivers[r]
+            lo, hi = shard_range(n, r, world)
+            d.upload_shard(clouds[0][lo:hi])
+            ticket = d.begin_exchange(0)
+            for step in range(2):
+                cur = d.end_exchange(ticket)
+                if step == 0:
+                    d.upload_shard(clouds[1][lo:hi])
+                    ticket = d.begin_exchange(1)                  # in flight during the pass below
+                d.run_device(cur)
+                results[(r, step)] = d.download() + (handles[r].timings()["grid_points"],)
+        except BaseException as e:                                # noqa: BLE001 -- reported by the main thread
+            errors.append((r, repr(e)))
+            gate.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    ref = capi.Handle(0)
+    for step in range(2):
+        ref.set_points(clouds[step])
+        ref.curvature(k, 0.0, capi.KNN_GRID)
+        _, K0, H0, _ = ref.get_fit(0, n, coefs=False, H2=False)
+        K = np.concatenate([results[(r, step)][0] for r in range(world)])
+        H = np.concatenate([results[(r, step)][1] for r in range(world)])
+        assert np.array_equal(K.view(np.uint32), K0.view(np.uint32)) and np.array_equal(H.view(np.uint32), H0.view(np.uint32)), step
+        assert all(results[(r, step)][2] < 0.45 * n for r in range(world))       # a quarter and its margin, not the cloud
     for d in drivers:
         d.close()
     for h in handles + [ref]:

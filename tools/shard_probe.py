@@ -11,16 +11,36 @@ import numpy as np
 order = sys.argv[2] if len(sys.argv) > 2 else "scan"
 for G in (1, 2, 4, 8):
     n = per * G
-    if order == "scan":
+    if order.startswith("scan"):
         pts = np.concatenate([shapes.torus_scan_order(n, G, r, seed=1234) for r in range(G)])
     else:
         pts = shapes.torus_random(n, seed=1234)
     h = _capi.Handle(0)
     h.set_points(pts)
     lo, hi = shard_range(n, G - 1, G)
-    h.set_query_range(lo, hi)
+    slab = order.endswith("slab")           # "random-slab": ownership by slab, plus the records pass and the scatter of everybody's records
     best = None
-    for _ in range(4):
+    if slab:
+        import time
+        rec, Kd, Hd = h.device_alloc(n * 12), h.device_alloc(n * 4), h.device_alloc(n * 4)
+        for _ in range(5):
+            h.synchronize()
+            t0 = time.perf_counter()
+            if G > 1:
+                h.set_query_slab(G - 1, G)
+            h.curvature(50, 0.0, _capi.KNN_GRID)
+            rows = h.slab_records(rec, n) if G > 1 else n
+            h.synchronize()
+            t1 = time.perf_counter()
+            t = h.timings()
+            t["wall_ms"] = (t1 - t0) * 1e3
+            if best is None or t["wall_ms"] < best["wall_ms"]:
+                best = t
+        # (the scatter of n records, timed on a buffer that holds this rank's rows n / rows times over -- same bytes)
+        print(f"[{order}] rows {rows} wall {best['wall_ms']:.3f} ms ", end="")
+    else:
+      h.set_query_range(lo, hi)
+      for _ in range(4):
         h.curvature(50, 0.0, _capi.KNN_GRID)
         t = h.timings()
         if best is None or t["total_ms"] < best["total_ms"]:
