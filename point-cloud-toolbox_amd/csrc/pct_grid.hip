@@ -79,6 +79,12 @@ struct PackAcc {
         s[2] += dz; ss[2] += dz * dz;
         ++cnt;
     }
+    __device__ void add_box(float x, float y, float z) {     // extent only (no moments)
+        mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+        mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+        mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        ++cnt;
+    }
     __device__ void commit(PackRed* part) {      // this block's record (plain stores)
         __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
         __shared__ double s_s[kBlock / 64][3], s_ss[kBlock / 64][3];
@@ -244,13 +250,61 @@ __device__ __forceinline__ int slab_bin(float x, float x0, float inv) {
     return min(max(b, 0), kSlabBins - 1);
 }
 
-__global__ __launch_bounds__(kBlock) void k_slab_hist(const float* __restrict__ xyz, int64_t n, int axis, float x0, float inv,
-                                                      unsigned* __restrict__ hist) {
+// four points = twelve consecutive floats = three 16-byte loads per lane, neighbouring lanes adjacent (the scalar
+// x / y / z loads of a 12-byte record reach a third of every line each).  VEC needs a 16-byte aligned array.
+template <bool VEC>
+__device__ __forceinline__ int load_four_points(const float* __restrict__ xyz, int64_t g, int64_t n, float (&v)[12]) {
+    const int64_t i0 = g * 4;
+    const int have = (int)min((int64_t)4, n - i0);
+    if (VEC && have == 4) {
+        const float4* q = (const float4*)(xyz + 3 * i0);
+        const float4 a = q[0], b = q[1], c = q[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    } else {
+        for (int j = 0; j < 12; ++j) v[j] = j < 3 * have ? xyz[3 * i0 + j] : 0.f;
+    }
+    return have;
+}
+
+// bounding box / finite check of the whole cloud, for the slab cut (count and moments are not needed)
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void k_cloud_box(const float* __restrict__ xyz, int64_t n, PackRed* __restrict__ parts) {
+    PackAcc acc;
+    acc.init();
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        float v[12];
+        const int have = load_four_points<VEC>(xyz, g, n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < have) {
+                const bool ok = isfinite(v[3 * j]) && isfinite(v[3 * j + 1]) && isfinite(v[3 * j + 2]);
+                acc.bad |= !ok;
+                if (ok) acc.add_box(v[3 * j], v[3 * j + 1], v[3 * j + 2]);
+            }
+        }
+    }
+    acc.commit(parts + blockIdx.x);
+}
+
+// (few, large blocks: every block ends with one global atomic per non-empty bin)
+constexpr int kSlabHistBlock = 1024;
+template <bool VEC>
+__global__ __launch_bounds__(kSlabHistBlock) void k_slab_hist(const float* __restrict__ xyz, int64_t n, int axis, float x0, float inv,
+                                                              unsigned* __restrict__ hist) {
+    constexpr int kBlock = kSlabHistBlock;
     __shared__ unsigned s_h[kSlabBins];
     for (int i = threadIdx.x; i < kSlabBins; i += kBlock) s_h[i] = 0;
     __syncthreads();
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock)
-        atomicAdd(&s_h[slab_bin(xyz[3 * i + axis], x0, inv)], 1u);
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        float v[12];
+        const int have = load_four_points<VEC>(xyz, g, n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (j < have) atomicAdd(&s_h[slab_bin(axis == 0 ? v[3 * j] : axis == 1 ? v[3 * j + 1] : v[3 * j + 2], x0, inv)], 1u);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < kSlabBins; i += kBlock)
         if (s_h[i]) atomicAdd(&hist[i], s_h[i]);
@@ -294,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void k_slab_cut(const unsigned* __restrict_
 
 // SLAB: the owned points are those of the slab (compacted to the front through a second counter, in whatever order the
 // blocks arrive: the public index rides in w); otherwise the rows [q_begin, q_end), in their own order.
-template <bool SLAB>
+template <bool SLAB, bool VEC>
 __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ xyz, int64_t n, Box3 box, int64_t q_begin,
                                                       int64_t q_end, SlabCut cut, float4* __restrict__ pts4, unsigned* __restrict__ kept_others,
                                                       PackRed* __restrict__ red, PackRed* __restrict__ parts) {
@@ -310,13 +364,20 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
     float px[16], py[16], pz[16];
     unsigned keep_bits = 0, own_bits = 0;
     int bad = 0;
+    // slot r of a thread = point 4 (chunk's first group + (r / 4) kBlock + thread) + r % 4: four consecutive points per
+    // 48-byte load (load_four_points)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+        float v[12];
+        load_four_points<VEC>(xyz, base / 4 + rr * kBlock + threadIdx.x, n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { px[4 * rr + j] = v[3 * j]; py[4 * rr + j] = v[3 * j + 1]; pz[4 * rr + j] = v[3 * j + 2]; }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int64_t i = base + r * kBlock + threadIdx.x;
-        px[r] = py[r] = pz[r] = 0.f;
+        const int64_t i = base + 4 * ((r >> 2) * kBlock + threadIdx.x) + (r & 3);
         bool keep = false, own = false;
         if (i < n) {
-            px[r] = xyz[3 * i + 0]; py[r] = xyz[3 * i + 1]; pz[r] = xyz[3 * i + 2];
             bad |= !(isfinite(px[r]) && isfinite(py[r]) && isfinite(pz[r]));
             if (SLAB) {
                 const int b = slab_bin(cut.axis == 0 ? px[r] : cut.axis == 1 ? py[r] : pz[r], cut.x0, cut.inv);
@@ -349,7 +410,7 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
         int total = 0;
         for (int r = 0; r < 16; ++r)
             for (int v = 0; v < kBlock / 64; ++v) { const int c = s_own[r][v]; s_own[r][v] = total; total += c; }
-        s_own_base = total ? (int)atomicAdd(kept_others + 1, (unsigned)total) : 0;
+        s_own_base = total ? (int)atomicAdd(kept_others + 32, (unsigned)total) : 0;       // (its own 128-byte line)
     }
     __syncthreads();
     const int64_t out0 = n_owned + s_base;
@@ -357,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
     for (int r = 0; r < 16; ++r) {
         const bool keep = (keep_bits >> r) & 1u;
         const unsigned long long m = __ballot(keep);
-        const int64_t i = base + r * kBlock + threadIdx.x;
+        const int64_t i = base + 4 * ((r >> 2) * kBlock + threadIdx.x) + (r & 3);
         if (keep) {
             const int64_t at = out0 + s_cnt[r][w] + (int)__popcll(m & ((1ull << lane) - 1ull));
             if (!SLAB || at < n) pts4[at] = make_float4(px[r], py[r], pz[r], __int_as_float((int)i));
@@ -719,11 +780,13 @@ int pct_pack_points(pct_ctx* ctx, float* bbox /*6*/) {
 static int slab_split(pct_ctx* ctx) {
     const int64_t n = ctx->n;
     const int parts = ctx->slab_parts;
-    const int nb = grid_1d(n, kBlock * 4, 512);
+    const int nb = grid_1d(n, kBlock * 4, 2048);
+    const bool vec = ((uintptr_t)ctx->xyz_view & 15) == 0;
     PackRed red;
     float ob[6];
     PCT_TRY(red_reset(ctx, nb));
-    PCT_LAUNCH(k_range_box, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, (int64_t)0, n, red_parts(ctx));
+    if (vec) PCT_LAUNCH(k_cloud_box<true>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, red_parts(ctx));
+    else PCT_LAUNCH(k_cloud_box<false>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     PCT_TRY(red_read(ctx, nb, &red, ob));
     if (red.bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
@@ -738,8 +801,9 @@ static int slab_split(pct_ctx* ctx) {
     PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 256 + kSlabBins * sizeof(unsigned)));
     unsigned* hist = (unsigned*)((char*)ctx->scan_tmp.p + 256);
     PCT_HIP(ctx, hipMemsetAsync(hist, 0, kSlabBins * sizeof(unsigned), ctx->stream));
-    PCT_LAUNCH(k_slab_hist, dim3(grid_1d(n, kBlock * 8, 1024)), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, axis, ctx->slab_x0,
-               ctx->slab_inv, hist);
+    const int nh = grid_1d(n, kSlabHistBlock * 4, 512);
+    if (vec) PCT_LAUNCH(k_slab_hist<true>, dim3(nh), dim3(kSlabHistBlock), 0, ctx->stream, ctx->xyz_view, n, axis, ctx->slab_x0, ctx->slab_inv, hist);
+    else PCT_LAUNCH(k_slab_hist<false>, dim3(nh), dim3(kSlabHistBlock), 0, ctx->stream, ctx->xyz_view, n, axis, ctx->slab_x0, ctx->slab_inv, hist);
     int* h_cut = (int*)(ctx->pin + 2560);                       // mapped pinned memory: the kernel writes the host's copy
     long long* h_counts = (long long*)(ctx->pin + 3072);
     PCT_LAUNCH(k_slab_cut, dim3(1), dim3(kBlock), 0, ctx->stream, (const unsigned*)hist, (long long)n, parts, h_cut, h_counts);
@@ -818,18 +882,19 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
 
     const int nchunk = (int)((n + kCullChunk - 1) / kCullChunk);
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));           // worst case: everything is kept
-    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 64));
+    PCT_TRY(pct_reserve(ctx, &ctx->scan_tmp, 256));
     PCT_TRY(red_reset(ctx, nchunk));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, 2 * sizeof(unsigned), ctx->stream));
+    PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, 33 * sizeof(unsigned), ctx->stream));
     const SlabCut cut = {ctx->slab_axis, ctx->slab_bin_lo, ctx->slab_bin_hi, ctx->slab_x0, ctx->slab_inv};
-    if (slab)
-        PCT_LAUNCH(k_cull_pack<true>, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end, cut,
-                   (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
-    else
-        PCT_LAUNCH(k_cull_pack<false>, dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, ctx->q_end, cut,
-                   (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx));
+    const bool vec = ((uintptr_t)ctx->xyz_view & 15) == 0;
+#define PCT_CULL(S, V) PCT_LAUNCH((k_cull_pack<S, V>), dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, \
+                                  ctx->q_end, cut, (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx))
+    if (slab) { if (vec) PCT_CULL(true, true); else PCT_CULL(true, false); }
+    else { if (vec) PCT_CULL(false, true); else PCT_CULL(false, false); }
+#undef PCT_CULL
     PCT_HIP(ctx, hipGetLastError());
-    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, 2 * sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 160, ctx->scan_tmp.p, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+    PCT_HIP(ctx, hipMemcpyAsync(ctx->pin + 164, (const unsigned*)ctx->scan_tmp.p + 32, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
     PCT_TRY(red_read(ctx, nchunk, red, bbox));
     if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
     if (slab && (int64_t)((const unsigned*)(ctx->pin + 160))[1] != n_owned)

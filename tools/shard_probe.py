@@ -9,9 +9,12 @@ from point_cloud_toolbox_amd.dist import shard_range
 per = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 import numpy as np
 order = sys.argv[2] if len(sys.argv) > 2 else "scan"
-for G in (1, 2, 4, 8):
+shape = sys.argv[3] if len(sys.argv) > 3 else "torus"
+for G in [int(g) for g in sys.argv[4].split(",")] if len(sys.argv) > 4 else (1, 2, 4, 8):
     n = per * G
-    if order.startswith("scan"):
+    if shape == "egg":
+        pts = shapes.egg_carton_random(n, seed=1234)          # BASELINE configs[3]'s surface, rows in no spatial order
+    elif order.startswith("scan"):
         pts = np.concatenate([shapes.torus_scan_order(n, G, r, seed=1234) for r in range(G)])
     else:
         pts = shapes.torus_random(n, seed=1234)
