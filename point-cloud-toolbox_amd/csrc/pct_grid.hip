@@ -85,11 +85,12 @@ struct PackAcc {
         mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         ++cnt;
     }
-    __device__ void commit(PackRed* part) {      // this block's record (plain stores)
-        __shared__ float s_mn[kBlock / 64][3], s_mx[kBlock / 64][3];
-        __shared__ double s_s[kBlock / 64][3], s_ss[kBlock / 64][3];
-        __shared__ int s_bad[kBlock / 64];
-        __shared__ unsigned s_cnt[kBlock / 64];
+    template <int NW = kBlock / 64>
+    __device__ void commit(PackRed* part) {      // this block's record (plain stores); NW = waves per block
+        __shared__ float s_mn[NW][3], s_mx[NW][3];
+        __shared__ double s_s[NW][3], s_ss[NW][3];
+        __shared__ int s_bad[NW];
+        __shared__ unsigned s_cnt[NW];
         for (int a = 0; a < 3; ++a) {
             mn[a] = wave_min(mn[a]);
             mx[a] = wave_max(mx[a]);
@@ -109,7 +110,7 @@ struct PackAcc {
             const int a = threadIdx.x;
             float lo = s_mn[0][a], hi = s_mx[0][a];
             double t = s_s[0][a], tt = s_ss[0][a];
-            for (int i = 1; i < kBlock / 64; ++i) {
+            for (int i = 1; i < NW; ++i) {
                 lo = fminf(lo, s_mn[i][a]); hi = fmaxf(hi, s_mx[i][a]);
                 t += s_s[i][a]; tt += s_ss[i][a];
             }
@@ -121,7 +122,7 @@ struct PackAcc {
         if (threadIdx.x == 3) {
             int b = 0;
             unsigned c = 0;
-            for (int i = 0; i < kBlock / 64; ++i) { b |= s_bad[i]; c += s_cnt[i]; }
+            for (int i = 0; i < NW; ++i) { b |= s_bad[i]; c += s_cnt[i]; }
             part->bad = b;
             part->cnt = c;
         }
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(kBlock) void k_box_stats(const float4* __restrict__
 // the owned rows' bounding box plus a margin can be neighbours (the sweep verifies that per query, see
 // pct_grid::lim_lo).  One pass: the owned rows go to the front of the packed array in their own order, the kept
 // others behind them in whatever order the blocks arrive (one counter increment per 4096-row chunk).
-constexpr int kCullChunk = kBlock * 16;
+constexpr int kCullBlock = 512;          // (fewer chunks = fewer ticket atomics on one address, the pass's bound)
+constexpr int kCullChunk = kCullBlock * 16;
 
 // Ownership by slab (pct_set_query_slab): bin of a coordinate along the cut axis.  Every rank evaluates this very
 // expression on the same bytes (the library is built with -ffp-contract=off), in the histogram and in the pack alike.
@@ -349,11 +351,12 @@ __global__ __launch_bounds__(kBlock) void k_slab_cut(const unsigned* __restrict_
 // SLAB: the owned points are those of the slab (compacted to the front through a second counter, in whatever order the
 // blocks arrive: the public index rides in w); otherwise the rows [q_begin, q_end), in their own order.
 template <bool SLAB, bool VEC>
-__global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ xyz, int64_t n, Box3 box, int64_t q_begin,
+__global__ __launch_bounds__(kCullBlock) void k_cull_pack(const float* __restrict__ xyz, int64_t n, Box3 box, int64_t q_begin,
                                                       int64_t q_end, SlabCut cut, float4* __restrict__ pts4, unsigned* __restrict__ kept_others,
                                                       PackRed* __restrict__ red, PackRed* __restrict__ parts) {
-    __shared__ int s_cnt[16][kBlock / 64];
-    __shared__ int s_own[16][kBlock / 64];
+    constexpr int kBlock = kCullBlock, NW = kCullBlock / 64;
+    __shared__ int s_cnt[16][NW];
+    __shared__ int s_own[16][NW];
     __shared__ int s_base, s_own_base;
     const float sh[3] = {0.f, 0.f, 0.f};
     PackAcc acc;
@@ -400,17 +403,24 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {            // exclusive prefix over (round, wave), one counter increment per chunk
-        int total = 0;
-        for (int r = 0; r < 16; ++r)
-            for (int v = 0; v < kBlock / 64; ++v) { const int c = s_cnt[r][v]; s_cnt[r][v] = total; total += c; }
-        s_base = total ? (int)atomicAdd(kept_others, (unsigned)total) : 0;
-    }
-    if (SLAB && threadIdx.x == 64) {
-        int total = 0;
-        for (int r = 0; r < 16; ++r)
-            for (int v = 0; v < kBlock / 64; ++v) { const int c = s_own[r][v]; s_own[r][v] = total; total += c; }
-        s_own_base = total ? (int)atomicAdd(kept_others + 32, (unsigned)total) : 0;       // (its own 128-byte line)
+    // exclusive prefix over (round, wave) by one wave per list, one counter increment per chunk
+    if (w == 0 || (SLAB && w == 1)) {
+        int* list = w == 0 ? &s_cnt[0][0] : &s_own[0][0];
+        constexpr int per = 16 * NW / 64;
+        int c[per], mine = 0;
+#pragma unroll
+        for (int j = 0; j < per; ++j) { c[j] = list[lane * per + j]; mine += c[j]; }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        int run = incl - mine;
+#pragma unroll
+        for (int j = 0; j < per; ++j) { list[lane * per + j] = run; run += c[j]; }
+        const int total = __shfl(incl, 63);
+        if (lane == 0) {
+            if (w == 0) s_base = total ? (int)atomicAdd(kept_others, (unsigned)total) : 0;
+            else s_own_base = total ? (int)atomicAdd(kept_others + 32, (unsigned)total) : 0;       // (its own 128-byte line)
+        }
     }
     __syncthreads();
     const int64_t out0 = n_owned + s_base;
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(kBlock) void k_cull_pack(const float* __restrict__ 
         }
     }
     if (__any(bad) && lane == 0) atomicOr(&red->bad, 1);
-    acc.commit(parts + blockIdx.x);
+    acc.commit<NW>(parts + blockIdx.x);
 }
 
 // double4 variant: native float64 coordinates ride along (w = index).
@@ -887,7 +897,7 @@ static int pack_near_owned(pct_ctx* ctx, double target, float* bbox, PackRed* re
     PCT_HIP(ctx, hipMemsetAsync(ctx->scan_tmp.p, 0, 33 * sizeof(unsigned), ctx->stream));
     const SlabCut cut = {ctx->slab_axis, ctx->slab_bin_lo, ctx->slab_bin_hi, ctx->slab_x0, ctx->slab_inv};
     const bool vec = ((uintptr_t)ctx->xyz_view & 15) == 0;
-#define PCT_CULL(S, V) PCT_LAUNCH((k_cull_pack<S, V>), dim3(nchunk), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, \
+#define PCT_CULL(S, V) PCT_LAUNCH((k_cull_pack<S, V>), dim3(nchunk), dim3(kCullBlock), 0, ctx->stream, ctx->xyz_view, n, box, ctx->q_begin, \
                                   ctx->q_end, cut, (float4*)ctx->pts4.p, (unsigned*)ctx->scan_tmp.p, (PackRed*)ctx->red.p, red_parts(ctx))
     if (slab) { if (vec) PCT_CULL(true, true); else PCT_CULL(true, false); }
     else { if (vec) PCT_CULL(false, true); else PCT_CULL(false, false); }
