@@ -1718,6 +1718,358 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
     }
 }
 
+// ---------------------------------------------------------------------------
+// k_knn_duo: k_knn_pair's scheme for rows of 65 .. 128 entries (k = 64 .. 127; BASELINE configs[4] asks for k = 80) --
+// a float32 cloud, the uniform cell list, a plain sweep.  ONE query per loop trip; its list is two registers per lane
+// (element = lane + 64 * register), and the two registers take the roles the two queries of a pair play in
+// k_knn_pair: the compaction handles two staged batches per block of instructions, the exact keys of survivors
+// `lane` and `lane + 64` are two interleaved fp64 chains, and the sorting network (pct_sort_duo.inc, the same
+// generator) sorts the two halves side by side and then merges them (element i against 127 - i, strides 32 .. 1).
+// Same proofs, same bit-identical rows as k_knn_fast<2, EPS, true, true>: what could not be proven goes to
+// the redo list.  Positions (and distances) of the survivors wait in LDS for the sorted order.
+// ---------------------------------------------------------------------------
+#include "pct_sort_duo.inc"
+
+__device__ __forceinline__ void sort_duo_asm(unsigned& ea, unsigned& eb, const SortLanes& c) {
+    unsigned ta, tb;
+    asm volatile(PCT_SORT_DUO_ASM
+                 : [ea] "+v"(ea), [eb] "+v"(eb), [ta] "=&v"(ta), [tb] "=&v"(tb)
+                 : [sel0] "v"(c.sel[0]), [sel1] "v"(c.sel[1]), [sel2] "v"(c.sel[2]), [sel3] "v"(c.sel[3]), [sel4] "v"(c.sel[4]),
+                   [sel5] "v"(c.sel[5]), [a31] "v"(c.a31), [a63] "v"(c.a63));
+    const unsigned lo = PCT_SORT_DUO_RESULT_A, hi = PCT_SORT_DUO_RESULT_B;
+    ea = lo;
+    eb = hi;
+}
+
+// Staging capacity: cells are sized for 0.35 (k + 1) points, a surface's 27-cell stencil then holds 12 - 14 cells' worth --
+// 400 - 470 candidates at k = 64 .. 80: 512 slots sent 8 % of the items (k = 64) to 30 % (k = 80) to the exact sweep,
+// 768 slots (4 waves per SIMD with the 16-bit survivor list) send a handful.
+constexpr int kDuoCap = 768;
+template <bool DIST>
+struct DuoLds {
+    float cx[kDuoCap], cy[kDuoCap], cz[kDuoCap];         // staged stencil, 12 B per candidate
+    unsigned short pend[128 + 8];                        // staged slot (| run << 10) of survivor s; (first: the run-start bit string)
+    int pay_p[128];                                      // sorted position of survivor s
+    float pay_d[DIST ? 128 : 1];                         // its float32 distance
+    int offc[16];                                        // sorted position - flat slot, per non-empty run
+};
+
+template <bool EPS, bool DIST>
+__global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
+    constexpr int CAP = kDuoCap, LIST = 128, SLOT_BITS = 7, KEY_BITS = 32 - SLOT_BITS;
+    static_assert(CAP % 128 == 0 && CAP <= 1024, "slot ids: 10 bits of slot, 4 bits of run index");
+    __shared__ DuoLds<DIST> L;
+    const int lane = lane_id();
+    const int item = (int)blockIdx.x;
+    if (item >= a.n_items) return;
+    const SortLanes sort_dir = make_sort_lanes();
+    const int* __restrict__ cs = a.cell_start;
+
+    // ---- the work item, its stencil and its queries: as in k_knn_pair -----------------------------------------------
+    const int2 it2 = a.items[item];
+    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+    const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+    const int cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
+    const int rem = cell - cz * (nx * ny);
+    const int cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
+    const int cx = rem - cy * nx;
+    const int c0 = cs[cell];
+    const int qs = c0 + chunk * a.items_q;
+    const int nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
+    const int row0 = a.own_start[cell] + chunk * a.items_q;
+
+    int run_s = 0, run_len = 0;
+    if (lane < 9) {
+        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+        if (z >= 0 && z < nz && y >= 0 && y < ny) {
+            const int row = (z * ny + y) * nx;
+            run_s = cs[row + max(cx - 1, 0)];
+            run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+        }
+    }
+    float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (lane < nq) my_q = a.pts[qs + lane];
+    int my_pre = 0, m = 0;
+    {
+        int acc = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            my_pre = lane == t ? acc : my_pre;
+            acc += __builtin_amdgcn_readlane(run_len, t);
+        }
+        m = acc;
+    }
+    if (m > CAP) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.redo_count, nq);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < nq) a.redo[base + lane] = row0 + lane;
+        if (a.stats && lane == 0) {
+            atomicAdd(&a.counters[1], 1ull);
+            atomicAdd(&a.counters[4], (unsigned long long)nq);
+        }
+        return;
+    }
+    unsigned slotx[CAP / 64];
+    {
+        unsigned* bits = (unsigned*)L.pend;
+        static_assert(sizeof(L.pend) >= CAP / 8, "the run-start bit string lives in the survivor list");
+        if (lane < CAP / 32) bits[lane] = 0u;
+        wave_lds_sync();
+        const bool nonempty = lane < 9 && run_len > 0;
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
+        if (nonempty) {
+            atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
+            L.offc[__builtin_amdgcn_mbcnt_lo((unsigned)ne, 0)] = run_s - my_pre;
+        }
+        wave_lds_sync();
+        float4 tmp[CAP / 64];
+        int ubase = -1;
+#pragma unroll
+        for (int b = 0; b < CAP / 64; ++b) {
+            tmp[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+            slotx[b] = (unsigned)(b * 64 + lane);
+            if (b * 64 < m) {
+                const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b]);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)bits[2 * b + 1]);
+                const unsigned long long B = ((unsigned long long)hi << 32) | lo;
+                const unsigned long long S = B >> 1;
+                const int s0 = ubase + (int)(lo & 1u);
+                const int u = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(S >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)S, (unsigned)s0));
+                ubase += (int)__popcll(B);
+                const int j = b * 64 + lane;
+                slotx[b] |= (unsigned)u << 10;
+                if (j < m) tmp[b] = a.pts[j + L.offc[u]];
+            }
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int b = 0; b < CAP / 64; ++b) {
+            const int j = b * 64 + lane;
+            if (j < m) {
+                L.cx[j] = tmp[b].x; L.cy[j] = tmp[b].y; L.cz[j] = tmp[b].z;
+            } else if ((b & ~1) * 64 < m) {
+                L.cx[j] = INFINITY; L.cy[j] = 0.f; L.cz[j] = 0.f;
+            }
+        }
+    }
+    wave_lds_sync();
+
+    const int k = a.k;
+    const double eps2 = EPS ? a.eps2 : (double)INFINITY;
+    constexpr double kKeyRange = 2.3;
+    const double edge = a.g.cell;
+    const double scale = (double)(1u << KEY_BITS) / (kKeyRange * edge * edge);
+    constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
+    unsigned my_gkey;
+    {
+        const double gx = ((double)my_q.x - a.g.ox) * a.g.inv_cell - cx;
+        const double gy = ((double)my_q.y - a.g.oy) * a.g.inv_cell - cy;
+        const double gz = ((double)my_q.z - a.g.oz) * a.g.inv_cell - cz;
+        const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
+        my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
+    }
+    const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
+    const float cell2f = (float)(edge * edge);
+    const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
+    float t_prev_f = 0.f;
+    unsigned long long redo_mask = 0ull;
+
+    char* const pos_item = (char*)(a.nbr_pos + (int64_t)row0 * a.pitch);
+    char* const dist_item = DIST ? (char*)(a.nbr_dist + (int64_t)row0 * a.pitch) : nullptr;
+    const unsigned pitch4 = (unsigned)a.pitch * 4u;
+    // list entry i = lane + 64 r  ->  table column i - 1
+    const unsigned lane_off0 = (unsigned)(lane - 1) * 4u, lane_off1 = (unsigned)(lane + 63) * 4u;
+    const bool col0 = lane >= 1 && lane <= k, col1 = lane + 64 <= k;
+    // entries 0 .. k are the ones whose order matters: all of register 0 (k >= 64), lanes 0 .. k - 64 of register 1
+    const unsigned long long order_hi = k - 64 >= 63 ? ~0ull : (2ull << (k - 64)) - 1ull;
+    const unsigned short* pend_hi = &L.pend[64];
+
+    const auto query_loop = [&](auto NBP_) {
+        constexpr int NBP = decltype(NBP_)::value, NBU = 2 * NBP;
+        for (int qi = 0; qi < nq; ++qi) {
+            const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
+            const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
+            const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
+            const double qx = (double)ax, qy = (double)ay, qz = (double)az;
+            // ---- float32 squared distances of all staged candidates (packed: two batches per instruction) ----------
+            float ap[NBU];
+#pragma unroll
+            for (int p2 = 0; p2 < NBP; ++p2) {
+                const int sa = p2 * 128 + lane, sb = sa + 64;
+                const float2v vx = {L.cx[sa], L.cx[sb]}, vy = {L.cy[sa], L.cy[sb]}, vz = {L.cz[sa], L.cz[sb]};
+                const float2v dx = vx - ax, dy = vy - ay, dz = vz - az;
+                float2v d = dx * dx;
+                d = __builtin_elementwise_fma(dy, dy, d);
+                d = __builtin_elementwise_fma(dz, dz, d);
+                ap[2 * p2] = d.x;
+                ap[2 * p2 + 1] = d.y;
+            }
+            // ---- threshold: k+1 <= #(d < T) <= LIST, never beyond the eps ball (wave-uniform search) -----------------
+            const float T_init = eps2a;
+            int tot = m;
+            if constexpr (EPS) {
+                tot = 0;
+#pragma unroll
+                for (int b = 0; b < NBU; ++b) tot += (int)__popcll(__builtin_amdgcn_ballot_w64(ap[b] < T_init));
+            }
+            const bool need = tot > LIST;
+            float T = T_init;
+            int cnt = tot;
+            unsigned bkey = 0xFFFFFFFFu;          // exact keys of the candidates the pre-selection cut are >= bkey
+            if (need) {
+                const float target = 0.5f * (float)(k + 1 + LIST);
+                float t = t_prev_f > 0.f ? t_prev_f : cell2f;
+                if (!(t < T_init)) t = 0.5f * T_init;
+                float lo = 0.f, hi = T_init;
+                bool found = false;
+#pragma unroll 1
+                for (int trial = 0; trial < 16; ++trial) {
+                    int c = 0;
+#pragma unroll
+                    for (int b = 0; b < NBU; ++b) c += (int)__popcll(__builtin_amdgcn_ballot_w64(ap[b] < t));
+                    if ((unsigned)(c - (k + 1)) <= (unsigned)(LIST - (k + 1))) { T = t; cnt = c; found = true; break; }
+                    const bool below = c < k + 1;
+                    lo = below ? t : lo;
+                    hi = below ? hi : t;
+                    float nt = t * target * __builtin_amdgcn_rcpf((float)c);
+                    if (!(nt > lo && nt < hi)) nt = hi < INFINITY ? 0.5f * (lo + hi) : 2.f * lo;
+                    if (__builtin_amdgcn_ballot_w64(!(nt > lo && nt < hi)) != 0ull) break;      // no float left between: a pile of equal distances
+                    t = nt;
+                }
+                if (!found || __builtin_amdgcn_ballot_w64(!(T >= 1e-30f)) != 0ull) { redo_mask |= 1ull << qi; continue; }
+                t_prev_f = T;
+                // smallest exact key a candidate cut by the float32 threshold can have (k_knn_pair)
+                bkey = (unsigned)fmin((double)T * (1.0 - 0x1p-20) * scale, 4294967294.0);
+            }
+            // ---- compact the staged slots of the survivors, two batches per block of instructions (k_knn_pair's
+            // hand-placed sequence; here both batches append to the same list)
+            {
+                unsigned wr = (unsigned)(uintptr_t)&L.pend[0], wr1;
+                const unsigned long long all = __builtin_amdgcn_read_exec();
+                wave_lds_sync();
+#pragma unroll
+                for (int b = 0; b < NBU; b += 2) {
+                    unsigned r0, r1, n0, n1;
+                    asm volatile(
+                        "v_cmp_gt_f32 vcc, %[t], %[ap0]\n"
+                        "v_cmp_gt_f32 s[96:97], %[t], %[ap1]\n"
+                        "s_bcnt1_i32_b64 %[n0], vcc\n"
+                        "v_mbcnt_lo_u32_b32 %[r0], vcc_lo, 0\n"
+                        "s_bcnt1_i32_b64 %[n1], s[96:97]\n"
+                        "v_mbcnt_lo_u32_b32 %[r1], s96, 0\n"
+                        "v_mbcnt_hi_u32_b32 %[r0], vcc_hi, %[r0]\n"
+                        "v_mbcnt_hi_u32_b32 %[r1], s97, %[r1]\n"
+                        "s_lshl1_add_u32 %[wr1], %[n0], %[wr]\n"
+                        "v_lshl_add_u32 %[r0], %[r0], 1, %[wr]\n"
+                        "v_lshl_add_u32 %[r1], %[r1], 1, %[wr1]\n"
+                        "s_mov_b64 exec, vcc\n"
+                        "ds_write_b16 %[r0], %[slot0]\n"
+                        "s_mov_b64 exec, s[96:97]\n"
+                        "ds_write_b16 %[r1], %[slot1]\n"
+                        "s_mov_b64 exec, %[all]\n"
+                        "s_lshl1_add_u32 %[wr], %[n1], %[wr1]\n"
+                        : [r0] "=&v"(r0), [r1] "=&v"(r1), [n0] "=&s"(n0), [n1] "=&s"(n1), [wr] "+s"(wr), [wr1] "=&s"(wr1)
+                        : [t] "v"(T), [ap0] "v"(ap[b]), [ap1] "v"(ap[b + 1]), [slot0] "v"(slotx[b]), [slot1] "v"(slotx[b + 1]), [all] "s"(all)
+                        : "vcc", "scc", "s96", "s97", "memory");
+                }
+                wave_lds_sync();
+            }
+            // ---- exact keys of survivors `lane` and `lane + 64` (two interleaved fp64 chains); a stale list entry is
+            // masked into the staging area and gives a garbage value nobody uses
+            const unsigned sx0 = (unsigned)L.pend[lane] & 0x3FFFu, sx1 = (unsigned)pend_hi[lane] & 0x3FFFu;      // slot | run << 10
+            const int j0 = min((int)(sx0 & 1023u), CAP - 1), j1 = min((int)(sx1 & 1023u), CAP - 1);
+            unsigned e[2];
+            {
+                const double dx0 = (double)L.cx[j0] - qx, dy0 = (double)L.cy[j0] - qy, dz0 = (double)L.cz[j0] - qz;
+                const double dx1 = (double)L.cx[j1] - qx, dy1 = (double)L.cy[j1] - qy, dz1 = (double)L.cz[j1] - qz;
+                const double d20 = (dx0 * dx0 + dy0 * dy0) + dz0 * dz0;
+                const double d21 = (dx1 * dx1 + dy1 * dy1) + dz1 * dz1;
+                L.pay_p[lane] = j0 + L.offc[sx0 >> 10];
+                L.pay_p[lane + 64] = j1 + L.offc[sx1 >> 10];
+                if constexpr (DIST) {
+                    L.pay_d[lane] = (float)sqrt(d20);
+                    L.pay_d[lane + 64] = (float)sqrt(d21);
+                }
+                const unsigned k0 = (min((unsigned)(d20 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)lane;
+                const unsigned k1 = (min((unsigned)(d21 * scale), key_max - 1u) << SLOT_BITS) | (unsigned)(lane + 64);
+                e[0] = lane < cnt && (!EPS || d20 < eps2) ? k0 : kPadElem;
+                e[1] = lane + 64 < cnt && (!EPS || d21 < eps2) ? k1 : kPadElem;
+            }
+            wave_lds_sync();
+            sort_duo_asm(e[0], e[1], sort_dir);
+            // ---- proof obligations (key units, see k_knn_fast) ----------------------------------------------------
+            const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)e[1], k - 64);     // the (k+1)-th nearest (padding if fewer exist)
+            const unsigned gk = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
+            const unsigned tk = tau >> SLOT_BITS;
+            const unsigned need_k = min(tau == kPadElem ? 0xFFFFFFFFu : tk + 1u, eps_key);
+            if (need_k > min(gk, bkey) || (tau != kPadElem && tk >= key_max - 1u)) { redo_mask |= 1ull << qi; continue; }
+            // equal keys among the first k + 2 entries: ordered here by the exact values (order_equal_keys).  Detection:
+            // element i ^ element i + 1 below 2^SLOT_BITS <=> same key
+            {
+                unsigned n0, n1;
+                asm("s_nop 1\n"
+                    "v_mov_b32_dpp %0, %2 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                    "v_mov_b32_dpp %1, %3 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+                    "s_nop 0"
+                    : "=&v"(n0), "=&v"(n1) : "v"(e[0]), "v"(e[1]));
+                n0 = lane == 63 ? (unsigned)__builtin_amdgcn_readlane((int)e[1], 0) : n0;        // entry 64 follows entry 63
+                const bool same0 = ((e[0] ^ n0) >> SLOT_BITS) == 0u && e[0] != kPadElem && n0 != kPadElem;
+                const bool same1 = ((e[1] ^ n1) >> SLOT_BITS) == 0u && e[1] != kPadElem && n1 != kPadElem && lane < 63;
+                const unsigned long long cm = __builtin_amdgcn_ballot_w64(same0) | (__builtin_amdgcn_ballot_w64(same1) & order_hi);
+                if (__builtin_expect(cm != 0ull, 0)) {
+                    const bool done = order_equal_keys<2, SLOT_BITS>(e, a.pts,
+                        [&](unsigned at) {
+                            const int j = min((int)L.pend[at] & 1023, CAP - 1);
+                            const double dx = (double)L.cx[j] - qx, dy = (double)L.cy[j] - qy, dz = (double)L.cz[j] - qz;
+                            return (dx * dx + dy * dy) + dz * dz;
+                        },
+                        [&](unsigned at) { return L.pay_p[at]; });
+                    if (!done) { redo_mask |= 1ull << qi; continue; }
+                }
+            }
+            // ---- store: the lane that holds list entry i looks up position (and distance) of survivor e & 127 --------
+            {
+                const unsigned off0 = lane_off0 + (unsigned)qi * pitch4, off1 = lane_off1 + (unsigned)qi * pitch4;
+                const bool real0 = e[0] != kPadElem, real1 = e[1] != kPadElem;
+                const int s0 = (int)(e[0] & 127u), s1 = (int)(e[1] & 127u);
+                const int pos0 = L.pay_p[s0], pos1 = L.pay_p[s1];
+                if (col0) *(int*)(pos_item + off0) = real0 ? pos0 : -1;
+                if (col1) *(int*)(pos_item + off1) = real1 ? pos1 : -1;
+                if constexpr (DIST) {
+                    const float d0 = L.pay_d[s0], d1 = L.pay_d[s1];
+                    if (col0) *(float*)(dist_item + off0) = real0 ? d0 : INFINITY;
+                    if (col1) *(float*)(dist_item + off1) = real1 ? d1 : INFINITY;
+                }
+                if constexpr (EPS) {
+                    const int f = (int)__popcll(__builtin_amdgcn_ballot_w64(real0 && col0)) + (int)__popcll(__builtin_amdgcn_ballot_w64(real1 && col1));
+                    if (lane == 0) a.nbr_cnt[row0 + qi] = f;
+                }
+            }
+            wave_lds_sync();          // the payload arrays are free for the next query
+        }
+    };
+    {
+        using std::integral_constant;
+        const int nbp = (m + 127) >> 7;
+        if (nbp <= 1) query_loop(integral_constant<int, 1>{});
+        else if (nbp == 2) query_loop(integral_constant<int, 2>{});
+        else if (nbp == 3) query_loop(integral_constant<int, 3>{});
+        else if (nbp == 4) query_loop(integral_constant<int, 4>{});
+        else if (nbp == 5) query_loop(integral_constant<int, 5>{});
+        else query_loop(integral_constant<int, 6>{});
+    }
+    if (redo_mask) {
+        const int cnt = (int)__popcll(redo_mask);
+        int base = 0;
+        if (lane == 0) base = atomicAdd(a.redo_count, cnt);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if ((redo_mask >> lane) & 1ull) a.redo[base + (int)__popcll(redo_mask & ((1ull << lane) - 1ull))] = row0 + lane;
+        if (a.stats && lane == 0) atomicAdd(&a.counters[4], (unsigned long long)cnt);
+    }
+}
+
 // cKDTree.query for caller-supplied points (pct_query_points): the exhaustive sweep with the query read from a
 // separate array and every element of the list stored (nothing is "the point itself" here).
 __global__ __launch_bounds__(256) void k_plain_records(const float* __restrict__ xyz, int64_t n, float4* __restrict__ out) {
@@ -1931,7 +2283,11 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
     const bool pair_kernel = !exact_only && phase == 0 && q64_ok_ && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
                              k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !pct_getenv("PCT_NO_PAIR") &&
                              !pct_getenv("PCT_NO_PAIR_KERNEL");
-    const bool skip_dist = pair_kernel && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
+    // rows of 65 .. 128 entries of a float32 cloud: the same scheme with two list registers (k_knn_duo)
+    const bool duo_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
+                            k + 1 > pct_fast_r1_max() && k >= 64 && k + 1 <= 128 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
+                            !pct_getenv("PCT_NO_PAIR") && !pct_getenv("PCT_NO_DUO_KERNEL");
+    const bool skip_dist = (pair_kernel || duo_kernel) && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
     if (phase != 2) {
         PCT_TRY(reserve_table(ctx, k, eps, !skip_dist));
         PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
@@ -1967,7 +2323,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
 #define PCT_FAST_PAIR64(R_, E_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, true, true, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
         // the plain sweep of a float32 cloud with one list register: the scalar-lean kernel (k_knn_pair)
-        if (pair_kernel) {
+        if (pair_kernel || duo_kernel) {
             PairArgs pa = {};
             pa.pts = a.pts; pa.ptsd = a.ptsd; pa.cell_start = a.cell_start; pa.cell_own = a.cell_own; pa.own_start = a.own_start;
             pa.items = items;
@@ -1985,6 +2341,13 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
             magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
             const dim3 gridp((unsigned)((ctx->n_items + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
+            if (duo_kernel) {
+                const dim3 gridd((unsigned)ctx->n_items), blockd(64);
+                if (e && skip_dist) PCT_LAUNCH((k_knn_duo<true, false>), gridd, blockd, 0, ctx->stream, pa);
+                else if (e) PCT_LAUNCH((k_knn_duo<true, true>), gridd, blockd, 0, ctx->stream, pa);
+                else if (skip_dist) PCT_LAUNCH((k_knn_duo<false, false>), gridd, blockd, 0, ctx->stream, pa);
+                else PCT_LAUNCH((k_knn_duo<false, true>), gridd, blockd, 0, ctx->stream, pa);
+            } else
             if (ctx->has_f64) {
                 if (e && skip_dist) PCT_LAUNCH((k_knn_pair<true, false, true>), gridp, blockp, 0, ctx->stream, pa);
                 else if (e) PCT_LAUNCH((k_knn_pair<true, true, true>), gridp, blockp, 0, ctx->stream, pa);

@@ -42,7 +42,10 @@ class Gen:
 DPP_CTRL = {1: "quad_perm:[1,0,3,2]", 2: "quad_perm:[2,3,0,1]", 8: "row_ror:8"}
 FLIP_CTRL = {2: "quad_perm:[1,0,3,2]", 4: "quad_perm:[3,2,1,0]", 8: "row_half_mirror", 16: "row_mirror"}
 
-def network(sets=("a", "b"), swz=()):
+def network(sets=("a", "b"), swz=(), duo=False):
+    """duo: the two sets are the lower and the upper 64 elements of ONE list of 128 (element = lane + 64 * set): after
+    both are sorted, one more merge -- element i against 127 - i (each set against the lane-reversed other one, the
+    smaller elements stay in set a), then the half-cleaners of strides 32 .. 1 on either set."""
     g = Gen()
     cur = {s: "e" + s for s in sets}      # register holding the set's elements
     tmp = {s: "t" + s for s in sets}
@@ -76,6 +79,26 @@ def network(sets=("a", "b"), swz=()):
             g.emit(f"v_permlane16_swap_b32 {e}, {t}", writes=[e, t], dpp_reads=[e, t])
             g.emit(f"v_med3_u32 {e}, {e}, {t}, {R(sel)}", writes=[e])
 
+    def swap32_level(sel):
+        for s in sets:
+            e, t = R(cur[s]), R(tmp[s])
+            g.emit(f"v_mov_b32 {t}, {e}", writes=[t])
+        for s in sets:
+            e, t = R(cur[s]), R(tmp[s])
+            g.emit(f"v_permlane32_swap_b32 {e}, {t}", writes=[e, t], dpp_reads=[e, t])
+            g.emit(f"v_med3_u32 {e}, {e}, {t}, {R(sel)}", writes=[e])
+
+    def flip128():
+        a, b = sets
+        ea, ta, eb, tb = R(cur[a]), R(tmp[a]), R(cur[b]), R(tmp[b])
+        g.emit(f"ds_bpermute_b32 {tb}, {R('a63')}, {eb}")
+        g.emit(f"ds_bpermute_b32 {ta}, {R('a63')}, {ea}")
+        g.emit("s_waitcnt lgkmcnt(1)")
+        g.emit(f"v_min_u32 {tb}, {ea}, {tb}", writes=[tb])      # lower half: min(a[i], b[63 - i])
+        g.emit("s_waitcnt lgkmcnt(0)")
+        g.emit(f"v_max_u32 {ta}, {eb}, {ta}", writes=[ta])      # upper half: max(b[i], a[63 - i])
+        cur[a], tmp[a], cur[b], tmp[b] = tmp[b], cur[a], tmp[a], cur[b]
+
     def bperm_level(addr, sel):
         for s in sets:
             e, t = R(cur[s]), R(tmp[s])
@@ -106,6 +129,8 @@ def network(sets=("a", "b"), swz=()):
             xor4_level()
         elif st == 16:
             swap16_level(sel)
+        elif st == 32:
+            swap32_level(sel)
         else:
             dpp_level(DPP_CTRL[st], sel)
 
@@ -124,18 +149,26 @@ def network(sets=("a", "b"), swz=()):
             stride(st)
             st //= 2
         size *= 2
+    if duo:
+        flip128()
+        st = 32
+        while st >= 1:
+            stride(st)
+            st //= 2
     g.out.append("s_nop 1")            # the caller's next instruction may be a DPP read of the result
     return g.out, cur
 
 if __name__ == "__main__":
     # levels (1..21 in network order) whose partner move goes through ds_swizzle instead of DPP / permlane / bpermute
-    swz = set(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 and sys.argv[1] else set()
-    lines, cur = network(swz=swz)
+    duo = len(sys.argv) > 1 and sys.argv[1] == "duo"        # python tools/gen_sort_asm.py duo > .../pct_sort_duo.inc
+    swz = set(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 and sys.argv[1] and not duo else set()
+    lines, cur = network(swz=swz, duo=duo)
+    name = "DUO" if duo else "PAIR"
     print("// generated by tools/gen_sort_asm.py %s -- do not edit" % " ".join(sys.argv[1:]))
     print("// result registers: set a in %%[%s], set b in %%[%s]" % (cur["a"], cur["b"]))
-    print("#define PCT_SORT_PAIR_RESULT_A %s" % cur["a"])
-    print("#define PCT_SORT_PAIR_RESULT_B %s" % cur["b"])
-    print("#define PCT_SORT_PAIR_ASM \\")
+    print("#define PCT_SORT_%s_RESULT_A %s" % (name, cur["a"]))
+    print("#define PCT_SORT_%s_RESULT_B %s" % (name, cur["b"]))
+    print("#define PCT_SORT_%s_ASM \\" % name)
     for l in lines:
         print('    "%s\\n" \\' % l)
     print('    ""')

@@ -6,11 +6,14 @@ import numpy as np
 import __graft_entry__ as ge
 ge.build()
 from point_cloud_toolbox_amd import _capi, shapes
-pts = shapes.torus_random(1_000_000, seed=1234)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+ks = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [50]
+pts = shapes.torus_random(n, seed=1234)
 h = _capi.Handle(0)
 h.set_points(pts)
 h.set_stats(True)
-for _ in range(3):
-    h.curvature(50, 0.0, _capi.KNN_GRID)
-t = h.timings()
-print({k: t[k] for k in ("redone_queries", "lds_overflows", "ring_fallbacks", "occupied_cells", "occupancy", "knn_ms", "knn_fast_ms")})
+for kk in ks:
+    for _ in range(3):
+        h.curvature(kk, 0.0, _capi.KNN_GRID)
+    t = h.timings()
+    print(kk, {k: t[k] for k in ("redone_queries", "lds_overflows", "ring_fallbacks", "occupied_cells", "occupancy", "knn_ms", "knn_fast_ms")}, flush=True)
