@@ -1882,8 +1882,9 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
     // list entry i = lane + 64 r  ->  table column i - 1
     const unsigned lane_off0 = (unsigned)(lane - 1) * 4u, lane_off1 = (unsigned)(lane + 63) * 4u;
     const bool col0 = lane >= 1 && lane <= k, col1 = lane + 64 <= k;
-    // entries 0 .. k are the ones whose order matters: all of register 0 (k >= 64), lanes 0 .. k - 64 of register 1
-    const unsigned long long order_hi = k - 64 >= 63 ? ~0ull : (2ull << (k - 64)) - 1ull;
+    // entries 0 .. k are the ones whose order matters: lanes 0 .. k of register 0, lanes 0 .. k - 64 of register 1
+    const unsigned long long order_lo = k >= 63 ? ~0ull : (2ull << k) - 1ull;
+    const unsigned long long order_hi = k < 64 ? 0ull : k - 64 >= 63 ? ~0ull : (2ull << (k - 64)) - 1ull;
     const unsigned short* pend_hi = &L.pend[64];
 
     const auto query_loop = [&](auto NBP_) {
@@ -2000,7 +2001,7 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
             wave_lds_sync();
             sort_duo_asm(e[0], e[1], sort_dir);
             // ---- proof obligations (key units, see k_knn_fast) ----------------------------------------------------
-            const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)e[1], k - 64);     // the (k+1)-th nearest (padding if fewer exist)
+            const unsigned tau = (unsigned)__builtin_amdgcn_readlane((int)(k < 64 ? e[0] : e[1]), k & 63);     // the (k+1)-th nearest (padding if fewer exist)
             const unsigned gk = (unsigned)__builtin_amdgcn_readlane((int)my_gkey, qi);
             const unsigned tk = tau >> SLOT_BITS;
             const unsigned need_k = min(tau == kPadElem ? 0xFFFFFFFFu : tk + 1u, eps_key);
@@ -2017,7 +2018,7 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
                 n0 = lane == 63 ? (unsigned)__builtin_amdgcn_readlane((int)e[1], 0) : n0;        // entry 64 follows entry 63
                 const bool same0 = ((e[0] ^ n0) >> SLOT_BITS) == 0u && e[0] != kPadElem && n0 != kPadElem;
                 const bool same1 = ((e[1] ^ n1) >> SLOT_BITS) == 0u && e[1] != kPadElem && n1 != kPadElem && lane < 63;
-                const unsigned long long cm = __builtin_amdgcn_ballot_w64(same0) | (__builtin_amdgcn_ballot_w64(same1) & order_hi);
+                const unsigned long long cm = (__builtin_amdgcn_ballot_w64(same0) & order_lo) | (__builtin_amdgcn_ballot_w64(same1) & order_hi);
                 if (__builtin_expect(cm != 0ull, 0)) {
                     const bool done = order_equal_keys<2, SLOT_BITS>(e, a.pts,
                         [&](unsigned at) {
@@ -2285,7 +2286,7 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
                              !pct_getenv("PCT_NO_PAIR_KERNEL");
     // rows of 65 .. 128 entries of a float32 cloud: the same scheme with two list registers (k_knn_duo)
     const bool duo_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
-                            k + 1 > pct_fast_r1_max() && k >= 64 && k + 1 <= 128 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
+                            k + 1 > pct_fast_r1_max() && k + 1 <= 128 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
                             !pct_getenv("PCT_NO_PAIR") && !pct_getenv("PCT_NO_DUO_KERNEL");
     const bool skip_dist = (pair_kernel || duo_kernel) && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
     if (phase != 2) {
