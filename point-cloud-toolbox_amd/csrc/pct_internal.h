@@ -200,8 +200,9 @@ void pct_comm_release(pct_ctx* ctx);
 // The fast sweep sorts <= 64 survivors in one register per lane (R = 1) or <= 128 in two (R = 2).  R = 1 would hold
 // k + 1 <= 64, but near that limit the window k+1 <= count <= 64 for the threshold gets narrow and the larger cells
 // overflow the 512-slot staging area: from k + 1 > kFastR1Max on, R = 2 (768 slots, window up to 128) is faster.
+// (Round 3, k_knn_pair against k_knn_duo on the 1 M torus: 0.51 | 0.60 ms at k = 56, 0.59 | 0.60 at 60, 0.80 | 0.61 at 63.)
 #ifndef PCT_FAST_R1_MAX
-#define PCT_FAST_R1_MAX 64
+#define PCT_FAST_R1_MAX 61
 #endif
 inline int pct_fast_r1_max() {
     static const int v = [] { const char* e = getenv("PCT_FAST_R1_MAX"); const int x = e ? atoi(e) : PCT_FAST_R1_MAX; return x < 2 ? 2 : x > 64 ? 64 : x; }();
