@@ -56,6 +56,8 @@ struct FitArgs {
     unsigned n_pts;          // records in pts: a table entry outside [0, n_pts) is never dereferenced (the row reads NaN)
     const int* row_mask;     // MASKED instantiation: only the rows with a non-zero entry are fitted (passes of the density-adaptive sweep)
     int svd_accumulate;      // the count of rows handed to k_fit_svd is ADDED to the host word (the passes of one fused call)
+    int blocks_per_xcd;      // blocks are dealt to the 8 XCDs in turn: block b takes rows of block (b % 8) * blocks_per_xcd + b / 8, so
+                             // that one XCD's L2 serves neighbouring rows (table rows are in cell order: their neighbours overlap)
 };
 
 // Smallest Cholesky pivot ratio d_j / g_jj (= sin^2 of the angle between design column j and the span of the columns
@@ -181,7 +183,8 @@ template <bool F64, bool OUT64 = false, bool STAGED = true, bool MASKED = false>
 __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     extern __shared__ int s_idx[];   // 64 rows x kp
     const int lane = threadIdx.x;
-    const int64_t row0 = (int64_t)blockIdx.x * kFitBlock;
+    const int64_t row0 = (a.blocks_per_xcd ? (int64_t)(blockIdx.x & 7u) * a.blocks_per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x) * kFitBlock;
+    if (row0 >= a.rows) return;
     const int k = a.k, kp = a.kp;
 
     // ---- stage 64 index rows: 16 lanes x int4 per row, 4 rows per load instruction, all loads independent
@@ -711,8 +714,10 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     size_t lds = (size_t)kFitBlock * a.kp * sizeof(int);
     const bool staged = lds <= 64 * 1024;                  // the default dynamic LDS limit of a launch
     if (!staged) lds = 0;
-    const int blocks = (int)((a.rows + kFitBlock - 1) / kFitBlock);
+    int blocks = (int)((a.rows + kFitBlock - 1) / kFitBlock);
     if (blocks <= 0) return PCT_OK;
+    a.blocks_per_xcd = pct_getenv("PCT_NO_XCD_MAP") ? 0 : (blocks + 7) / 8;
+    if (a.blocks_per_xcd) blocks = a.blocks_per_xcd * 8;
     // rows for k_fit_svd: list + its length (first word of the buffer's 64-byte head)
     PCT_TRY(pct_reserve(ctx, &ctx->fit_flag, 64 + (size_t)a.rows * sizeof(int)));
     PCT_HIP(ctx, hipMemsetAsync(ctx->fit_flag.p, 0, 64, ctx->stream));

@@ -189,17 +189,43 @@ __global__ __launch_bounds__(kBlock) void k_pack_final(const PackRed* __restrict
 
 // xyz (n,3) -> float4 {x,y,z,index}; finite check; bbox and moments (fp64, about the origin: the reference
 // shifts every cloud by its per-axis maximum, pct:56-57, so coordinates are of the order of the extent).
+// four points = twelve consecutive floats = three 16-byte loads per lane, neighbouring lanes adjacent (the scalar
+// x / y / z loads of a 12-byte record reach a third of every line each).  VEC needs a 16-byte aligned array.
+template <bool VEC>
+__device__ __forceinline__ int load_four_points(const float* __restrict__ xyz, int64_t g, int64_t n, float (&v)[12]) {
+    const int64_t i0 = g * 4;
+    const int have = (int)min((int64_t)4, n - i0);
+    if (VEC && have == 4) {
+        const float4* q = (const float4*)(xyz + 3 * i0);
+        const float4 a = q[0], b = q[1], c = q[2];
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+    } else {
+        for (int j = 0; j < 12; ++j) v[j] = j < 3 * have ? xyz[3 * i0 + j] : 0.f;
+    }
+    return have;
+}
+
+template <bool VEC>
 __global__ __launch_bounds__(kBlock) void k_pack(const float* __restrict__ xyz, int64_t n,
                                                  float4* __restrict__ pts4, PackRed* __restrict__ parts) {
     const float sh[3] = {0.f, 0.f, 0.f};
     PackAcc acc;
     acc.init();
-    for (int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
-        acc.bad |= !ok;
-        pts4[i] = make_float4(x, y, z, __int_as_float((int)i));
-        if (ok) acc.add(x, y, z, sh);
+    const int64_t groups = (n + 3) / 4;
+    for (int64_t g = (int64_t)blockIdx.x * kBlock + threadIdx.x; g < groups; g += (int64_t)gridDim.x * kBlock) {
+        float v[12];
+        const int have = load_four_points<VEC>(xyz, g, n, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < have) {
+                const float x = v[3 * j], y = v[3 * j + 1], z = v[3 * j + 2];
+                const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+                acc.bad |= !ok;
+                pts4[4 * g + j] = make_float4(x, y, z, __int_as_float((int)(4 * g + j)));
+                if (ok) acc.add(x, y, z, sh);
+            }
+        }
     }
     acc.commit(parts + blockIdx.x);
 }
@@ -250,23 +276,6 @@ struct SlabCut { int axis, bin_lo, bin_hi; float x0, inv; };
 __device__ __forceinline__ int slab_bin(float x, float x0, float inv) {
     const int b = (int)((x - x0) * inv);
     return min(max(b, 0), kSlabBins - 1);
-}
-
-// four points = twelve consecutive floats = three 16-byte loads per lane, neighbouring lanes adjacent (the scalar
-// x / y / z loads of a 12-byte record reach a third of every line each).  VEC needs a 16-byte aligned array.
-template <bool VEC>
-__device__ __forceinline__ int load_four_points(const float* __restrict__ xyz, int64_t g, int64_t n, float (&v)[12]) {
-    const int64_t i0 = g * 4;
-    const int have = (int)min((int64_t)4, n - i0);
-    if (VEC && have == 4) {
-        const float4* q = (const float4*)(xyz + 3 * i0);
-        const float4 a = q[0], b = q[1], c = q[2];
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-        v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-    } else {
-        for (int j = 0; j < 12; ++j) v[j] = j < 3 * have ? xyz[3 * i0 + j] : 0.f;
-    }
-    return have;
 }
 
 // bounding box / finite check of the whole cloud, for the slab cut (count and moments are not needed)
@@ -759,10 +768,12 @@ static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
 static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red, bool defer = false) {
     const int64_t n = ctx->n;
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));
-    const int nb = grid_1d(n, kBlock * 4, 512);
+    const int nb = grid_1d(n, kBlock * 4, 2048);
     PCT_TRY(red_reset(ctx, nb));
-    PCT_LAUNCH(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream,
-                       ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
+    if (((uintptr_t)ctx->xyz_view & 15) == 0)
+        PCT_LAUNCH(k_pack<true>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
+    else
+        PCT_LAUNCH(k_pack<false>, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     if (defer) {
         PCT_TRY(red_fold(ctx, nb));

@@ -1220,6 +1220,8 @@ struct PairArgs {
     int* redo_count;
     unsigned long long* counters;
     int n_items, items_q;
+    int items_per_xcd;        // blocks are dealt to the 8 XCDs in turn: block b takes item (b % 8) * items_per_xcd + b / 8, so that
+                              // the items one XCD's L2 serves at a time are neighbours in cell order (they share most of their stencils)
     int k, pitch;
     int stats;
     unsigned magic_x, magic_xy;      // cell -> (cx, cy, cz) by multiplication: q = (x * magic) >> shift, exact for x < 2^30
@@ -1255,8 +1257,9 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
     __shared__ PairLds s_lds[kPairWaves];
     const int w = kPairWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
-    const int item = (int)blockIdx.x * kPairWaves + w;
-    if (item >= a.n_items) return;
+    const int blk = (int)blockIdx.x * kPairWaves + w;
+    const int item = a.items_per_xcd ? (blk & 7) * a.items_per_xcd + (blk >> 3) : blk;
+    if (item >= a.n_items || (a.items_per_xcd && (blk >> 3) >= a.items_per_xcd)) return;
     PairLds& L = s_lds[w];
     const SortLanes sort_dir = make_sort_lanes();
     const int* __restrict__ cs = a.cell_start;
@@ -1760,7 +1763,7 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
     static_assert(CAP % 128 == 0 && CAP <= 1024, "slot ids: 10 bits of slot, 4 bits of run index");
     __shared__ DuoLds<DIST> L;
     const int lane = lane_id();
-    const int item = (int)blockIdx.x;
+    const int item = a.items_per_xcd ? ((int)blockIdx.x & 7) * a.items_per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     if (item >= a.n_items) return;
     const SortLanes sort_dir = make_sort_lanes();
     const int* __restrict__ cs = a.cell_start;
@@ -2341,9 +2344,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             };
             magic((unsigned)a.g.nx, &pa.magic_x, &pa.shift_x);
             magic((unsigned)a.g.nx * (unsigned)a.g.ny, &pa.magic_xy, &pa.shift_xy);
-            const dim3 gridp((unsigned)((ctx->n_items + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
+            pa.items_per_xcd = (int)((ctx->n_items + 7) / 8);
+            if (pct_getenv("PCT_NO_XCD_MAP")) pa.items_per_xcd = 0;
+            const int64_t n_blk = pa.items_per_xcd ? (int64_t)pa.items_per_xcd * 8 : ctx->n_items;
+            const dim3 gridp((unsigned)((n_blk + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
             if (duo_kernel) {
-                const dim3 gridd((unsigned)ctx->n_items), blockd(64);
+                const dim3 gridd((unsigned)n_blk), blockd(64);
                 if (e && skip_dist) PCT_LAUNCH((k_knn_duo<true, false>), gridd, blockd, 0, ctx->stream, pa);
                 else if (e) PCT_LAUNCH((k_knn_duo<true, true>), gridd, blockd, 0, ctx->stream, pa);
                 else if (skip_dist) PCT_LAUNCH((k_knn_duo<false, false>), gridd, blockd, 0, ctx->stream, pa);
