@@ -309,7 +309,21 @@ struct ShellIter {
     int r_lo, ring, zlo, ylo, wy, nrows, row, part, pos, end, chunk;
     unsigned long long live;        // rows of the current chunk that hold at least one point
     int b_s0, b_e0, b_s1, b_e1;     // per lane: bounds of the (up to two) runs of row chunk + lane
-    __device__ __forceinline__ void start(const pct_grid& g, int cy, int cz, int lo, int hi) {
+    // Pruning: once the list is full, a cell whose box lies farther from the query than the current (k+1)-th distance
+    // cannot change it (a candidate replaces an entry only if it is nearer, or as near with a smaller index: a point
+    // strictly farther never does).  prune = that squared distance in cell units, shrunk bounds (1 - 1e-6, as in
+    // guaranteed_r2) on the cell side; +inf = keep everything.  Rows wholly beyond it are dropped, the others keep the
+    // cells of their x-range that can reach.  Clamped points (outside the grid box, filed in a boundary cell) lie
+    // beyond that cell's outer face: never nearer than the box says.
+    // (slack: cell coordinates are fl(fl(x - o) inv) -- two roundings of a number of up to n cells, or of the distance of
+    // a clamped query from the box: an absolute error of that many ulps, taken off every gap)
+    double prune, gx, gy, gz, slack;
+    __device__ __forceinline__ void start(const pct_grid& g, int cy, int cz, int lo, int hi, double prune_d2 = INFINITY,
+                                          double qgx = 0.0, double qgy = 0.0, double qgz = 0.0) {
+        const double ce = g.cell * (1.0 - 1e-6);
+        prune = prune_d2 / (ce * ce);
+        gx = qgx; gy = qgy; gz = qgz;
+        slack = 1e-15 * ((double)g.nx + (double)g.ny + (double)g.nz + fabs(qgx) + fabs(qgy) + fabs(qgz));
         r_lo = lo; ring = hi;
         zlo = max(-hi, -cz);
         ylo = max(-hi, -cy);
@@ -325,14 +339,32 @@ struct ShellIter {
             const int dz = zlo + ri / wy, dy = ylo + ri % wy;
             const int base = ((cz + dz) * g.ny + (cy + dy)) * g.nx;
             const bool inner = max(abs(dz), abs(dy)) <= r_lo;      // the row crosses the cube already searched
-            if (!inner) {
-                b_s0 = cs[base + max(cx - ring, 0)];
-                b_e0 = cs[base + min(cx + ring, g.nx - 1) + 1];
-            } else {
-                const int a0 = max(cx - ring, 0), a1 = cx - r_lo - 1;        // left of the searched cube
-                const int c0 = cx + r_lo + 1, c1 = min(cx + ring, g.nx - 1); // right of it
-                if (a1 >= a0) { b_s0 = cs[base + a0]; b_e0 = cs[base + a1 + 1]; }
-                if (c1 >= c0) { b_s1 = cs[base + c0]; b_e1 = cs[base + c1 + 1]; }
+            // x-range of the row the pruning bound leaves: offsets [x_lo, x_hi] around cx (empty: x_lo > x_hi)
+            int x_lo = -ring, x_hi = ring;
+            if (prune < INFINITY) {
+                const double ty = dy > 0 ? fmax(dy - gy - slack, 0.0) : dy < 0 ? fmax(gy - (dy + 1) - slack, 0.0) : 0.0;
+                const double tz = dz > 0 ? fmax(dz - gz - slack, 0.0) : dz < 0 ? fmax(gz - (dz + 1) - slack, 0.0) : 0.0;
+                const double left = prune - (ty * ty + tz * tz);
+                if (left < 0.0) { x_lo = 1; x_hi = 0; }
+                else {
+                    const double rx = sqrt(left) * (1.0 + 1e-9) + 1e-9 + slack;
+                    // offset dx > 0 reaches if dx - gx <= rx; dx < 0 if gx - (dx + 1) <= rx
+                    x_hi = (int)fmin((double)ring, floor(rx + gx));
+                    x_lo = -(int)fmin((double)ring, floor(rx + 1.0 - gx));
+                    x_hi = max(x_hi, 0);                         // (the query's own column always stays)
+                    x_lo = min(x_lo, 0);
+                }
+            }
+            if (x_lo <= x_hi) {
+                if (!inner) {
+                    b_s0 = cs[base + max(cx + x_lo, 0)];
+                    b_e0 = cs[base + min(cx + x_hi, g.nx - 1) + 1];
+                } else {
+                    const int a0 = max(cx + x_lo, 0), a1 = cx - r_lo - 1;        // left of the searched cube
+                    const int c0 = cx + r_lo + 1, c1 = min(cx + x_hi, g.nx - 1); // right of it
+                    if (a1 >= a0) { b_s0 = cs[base + a0]; b_e0 = cs[base + a1 + 1]; }
+                    if (c1 >= c0) { b_s1 = cs[base + c0]; b_e1 = cs[base + c1 + 1]; }
+                }
             }
         }
         live = __builtin_amdgcn_ballot_w64(b_e0 > b_s0 || b_e1 > b_s1);
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void k_knn_exact(KnnArgs a, co
             }
             // widen: one ring at a time near the query, then by half the radius (a query clamped into a corner of a
             // large empty grid must not pay one round per ring; the guarantee is that of the outer radius)
-            it.start(g, cy, cz, it.ring, it.ring < 4 ? it.ring + 1 : it.ring + (it.ring + 1) / 2);
+            it.start(g, cy, cz, it.ring, it.ring < 4 ? it.ring + 1 : it.ring + (it.ring + 1) / 2, fmin(sw.tau_d, sw.eps2), gx, gy, gz);
             have_next = it.next(g, cs, cx, cy, cz, nbase, nlim);
             if (have_next && nbase + lane < nlim) c_next = a.pts[nbase + lane];
         }
