@@ -42,6 +42,22 @@ json.dump({"kernel": "k_knn_pair<false,false> (the fused step's sweep: index tab
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (two separate passes, tools/profile_round.sh)"},
           open(o + "/knn_traffic.json", "w"), indent=1)
 PY
+# BASELINE configs[3] / [4] on one GPU (C5: k = 80 -> k_knn_duo), each checked against its 2000 sampled reference rows
+python bench.py --config c4 --no-extras --no-cpu-baseline --steps 5 --warmup 2 --verify > $O/bench_c4.json 2> $O/bench_c4.err
+python bench.py --config c5 --no-extras --no-cpu-baseline --steps 5 --warmup 2 --verify > $O/bench_c5.json 2> $O/bench_c5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5 -- python3 bench.py --config c5 --no-extras --no-cpu-baseline --steps 3 --warmup 1 > $O/c5.log 2>&1
+find $O/c5 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/c5_kernel_stats.csv
+rm -rf $O/c5
+echo c4 c5 done
+# one rank's step of a 4-way job on the unsorted 5 M-point egg carton, ownership by slab (and by index range, for comparison)
+python tools/shard_probe.py 1250000 random-slab egg 1,4 > $O/shard_probe_slab.txt 2>&1
+python tools/shard_probe.py 1250000 random egg 1,4 >> $O/shard_probe_slab.txt 2>&1
+python tools/shard_probe.py 1000000 scan torus > $O/shard_probe_scan.txt 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/slab -- python3 tools/shard_probe.py 1250000 random-slab egg 4 > $O/slab.log 2>&1
+find $O/slab -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/slab_rank_step_kernel_stats.csv
+rm -rf $O/slab
+python tools/redo_probe.py 1000000 50,61,64,80,100 > $O/redo_probe.txt 2>&1
+echo shard done
 # keep only the summaries (the raw traces are large)
 rm -rf $O/stats $O/fetch $O/write $O/sq1 $O/sq2 $O/lat
 ls -la $O
