@@ -382,10 +382,16 @@ def main():
     # PCT_BENCH_RAMP_MS=0 switches it off.
     ramp_ms = float(os.environ.get("PCT_BENCH_RAMP_MS", "60"))
     ramp_steps = 0
-    t_r = time.perf_counter()
-    while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
-        step()
-        ramp_steps += 1
+    if dist_mode:
+        # (every rank must issue the same collectives: a step count fixed from the request, not from a rank's clock)
+        for _ in range(int(ramp_ms / 2.0)):
+            step()
+            ramp_steps += 1
+    else:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+            step()
+            ramp_steps += 1
     for _ in range(args.warmup):
         step()
     dt, acc, last_tm = timed_region(args.steps)
