@@ -1086,7 +1086,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
 
     PCT_TRY(pct_reserve(ctx, &ctx->cell_of, (size_t)n * sizeof(int)));
     PCT_TRY(pct_reserve(ctx, &ctx->cell_fill, (size_t)n * sizeof(int)));   // in-cell arrival ranks
-    int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
+    // queries per work item: 16 - 20 measured best for k_knn_pair and k_knn_duo (one staged stencil serves more queries; a
+    // cell of ~28 points is one or two items; 1 M torus, k = 50: sweep 0.376 | 0.366 | 0.363 | 0.364 | 0.370 ms at 12 | 14 | 18 |
+    // 20 | 24; the reference's lattice torus 0.510 | 0.489 | 0.500 at 12 | 16 | 18; k = 80: 0.597 | 0.574 | 0.583 --
+    // tools/items_q_probe.py, tools/lattice_probe.py)
+    int items_q = 16;
     if (const char* e = pct_getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }   // tuning aid
     ctx->items_q = items_q;
     PCT_TRY(pct_reserve(ctx, &ctx->sorted4, (size_t)n * sizeof(float4)));

@@ -327,7 +327,7 @@ int pct_build_tree(pct_ctx* ctx, int32_t k, double eps, bool* usable) {
     g.nx = g.ny = g.nz = 1 << kTreeBits;
     g.ncell = 0;
     for (int a = 0; a < 3; ++a) { g.lim_lo[a] = -INFINITY; g.lim_hi[a] = INFINITY; }
-    int items_q = ctx->items_q > 0 && ctx->items_q <= 64 ? ctx->items_q : 12;
+    int items_q = 12;
     if (const char* e = pct_getenv("PCT_ITEMS_Q")) { const int v = atoi(e); if (v >= 1 && v <= 64) items_q = v; }
     ctx->items_q = items_q;
     double f_min = 0.45;
