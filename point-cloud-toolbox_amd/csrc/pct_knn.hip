@@ -9,7 +9,7 @@
 // by public index so the result does not depend on the cell order.
 //
 // Kernels (all hand-written for gfx950, 64-lane waves):
-//   k_knn_fast   one wave = one work item (a cell and <= 12 of its owned queries).  The 27-cell stencil is staged
+//   k_knn_fast   one wave = one work item (a cell and <= items_q of its owned queries).  The 27-cell stencil is staged
 //                once into LDS (12 B per candidate, all global loads in flight together), the item's queries are
 //                prefetched into registers.  Per PAIR of queries: float32 squared distances of all staged
 //                candidates in packed arithmetic, a threshold that leaves k+1 .. 64 R of them (ballot counts,
