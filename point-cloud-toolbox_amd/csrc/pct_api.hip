@@ -538,7 +538,10 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
 
 static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
     unsigned long long* c = (unsigned long long*)(ctx->pin + 192);       // pinned: a plain DMA, no staging
-    PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));   // [7] low word: rows on the redo list
+    // (the fused call's fit kernel has already written them there: one launch less in the step's tail)
+    if (!ctx->stats_mirrored)
+        PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));   // [7] low word: rows on the redo list
+    ctx->stats_mirrored = false;
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->tm.ring_fallbacks = (int64_t)c[0];
     ctx->tm.lds_overflows = (int64_t)c[1];
@@ -601,7 +604,10 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         bool again = false;
         PCT_TRY(run_knn(ctx, k, eps, algo, true));
         PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+        ctx->stats_mirrored = false;
+        ctx->stats_mirror_req = true;
         PCT_TRY(pct_launch_fit_table(ctx));
+        ctx->stats_mirror_req = false;
         PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
         PCT_TRY(finish_knn_stats(ctx, &again));
         if (!again) break;

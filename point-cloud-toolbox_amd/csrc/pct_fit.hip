@@ -53,6 +53,9 @@ struct FitArgs {
     double* H64;
     int* flag_list;          // rows k_fit hands to k_fit_svd (ill-conditioned or under-determined design matrices)
     int* flag_count;
+    int* flag_next;          // the count the NEXT launch will use: zeroed by this launch's first block (saves a memset launch)
+    const unsigned long long* stat_src;   // fused call: the sweep's eight statistics words ...
+    unsigned long long* stat_dst;         // ... copied to pinned host memory by the first block (saves a D2H copy)
     unsigned n_pts;          // records in pts: a table entry outside [0, n_pts) is never dereferenced (the row reads NaN)
     const int* row_mask;     // MASKED instantiation: only the rows with a non-zero entry are fitted (passes of the density-adaptive sweep)
     int svd_accumulate;      // the count of rows handed to k_fit_svd is ADDED to the host word (the passes of one fused call)
@@ -183,6 +186,10 @@ template <bool F64, bool OUT64 = false, bool STAGED = true, bool MASKED = false>
 __global__ __launch_bounds__(kFitBlock) void k_fit(FitArgs a) {
     extern __shared__ int s_idx[];   // 64 rows x kp
     const int lane = threadIdx.x;
+    if (blockIdx.x == 0) {
+        if (lane == 0 && a.flag_next) *a.flag_next = 0;
+        if (a.stat_dst && lane < 8) a.stat_dst[lane] = a.stat_src[lane];
+    }
     const int64_t row0 = (a.blocks_per_xcd ? (int64_t)(blockIdx.x & 7u) * a.blocks_per_xcd + (blockIdx.x >> 3) : (int64_t)blockIdx.x) * kFitBlock;
     if (row0 >= a.rows) return;
     const int k = a.k, kp = a.kp;
@@ -719,9 +726,26 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     a.blocks_per_xcd = pct_getenv("PCT_NO_XCD_MAP") ? 0 : (blocks + 7) / 8;
     if (a.blocks_per_xcd) blocks = a.blocks_per_xcd * 8;
     // rows for k_fit_svd: list + its length (first word of the buffer's 64-byte head)
+    // two counts used in turn: a launch counts in one and clears the other for the launch after it (both cleared once per
+    // allocation) -- the 64-byte memset in front of every fit was a launch of its own, 4 us and a dispatch gap
     PCT_TRY(pct_reserve(ctx, &ctx->fit_flag, 64 + (size_t)a.rows * sizeof(int)));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->fit_flag.p, 0, 64, ctx->stream));
-    a.flag_count = (int*)ctx->fit_flag.p;
+    if (ctx->fit_flag.p != ctx->fit_flag_seen || ctx->fit_flag.cap != ctx->fit_flag_cap_seen) {
+        PCT_HIP(ctx, hipMemsetAsync(ctx->fit_flag.p, 0, 64, ctx->stream));
+        ctx->fit_flag_seen = ctx->fit_flag.p;
+        ctx->fit_flag_cap_seen = ctx->fit_flag.cap;
+        ctx->fit_parity = 0;
+    }
+    a.stat_src = nullptr;
+    a.stat_dst = nullptr;
+    if (ctx->stats_mirror_req && ctx->counters.p) {
+        a.stat_src = (const unsigned long long*)ctx->counters.p;
+        a.stat_dst = (unsigned long long*)(ctx->pin + 192);
+        ctx->stats_mirrored = true;
+    }
+    ctx->stats_mirror_req = false;
+    a.flag_count = (int*)ctx->fit_flag.p + ctx->fit_parity;
+    a.flag_next = (int*)ctx->fit_flag.p + (ctx->fit_parity ^ 1);
+    ctx->fit_parity ^= 1;
     a.flag_list = (int*)ctx->fit_flag.p + 16;
 #define PCT_FIT_LAUNCH(F_, O_)                                                                                      \
     do {                                                                                                            \

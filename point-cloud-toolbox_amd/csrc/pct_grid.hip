@@ -614,9 +614,11 @@ __global__ __launch_bounds__(kBlock) void k_scan_sums(const int* __restrict__ ow
 // single block: exclusive scan of the per-tile sums; totals to tmp[nblk]
 struct ScanTotals { unsigned long long sumsq; int4 tot; };
 
+// (also clears the sweep's eight statistics words and its redo count, which saves the sweep a 64-byte memset launch)
 __global__ __launch_bounds__(1024) void k_scan_tiles(int4* __restrict__ tmp, int nblk, const unsigned long long* __restrict__ sq_part,
-                                                      ScanTotals* __restrict__ host_copy) {
+                                                      ScanTotals* __restrict__ host_copy, unsigned long long* __restrict__ zero8) {
     __shared__ int4 sh[1024];
+    if (zero8 && threadIdx.x < 8) zero8[threadIdx.x] = 0ull;
     __shared__ int4 carry;
     __shared__ unsigned long long shq[16];
     {   // sum of the per-tile sum-of-squares partials
@@ -1174,8 +1176,10 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_LAUNCH(k_scan_sums, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (int4*)ctx->scan_tmp.p, sq_part);
+        PCT_TRY(pct_reserve(ctx, &ctx->counters, 64 * sizeof(unsigned long long)));
         PCT_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
-                           (const unsigned long long*)sq_part, (ScanTotals*)(ctx->pin + 128));
+                           (const unsigned long long*)sq_part, (ScanTotals*)(ctx->pin + 128), (unsigned long long*)ctx->counters.p);
+        ctx->counters_clean = true;
         PCT_LAUNCH(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);

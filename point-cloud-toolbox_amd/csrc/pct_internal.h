@@ -166,6 +166,12 @@ struct pct_ctx {
     int32_t k = 0;
     int32_t nbr_pitch = 0;   // row pitch of nbr_pos / nbr_dist in elements (k rounded up to 4)
     double eps = 0.0;
+    bool counters_clean = false;   // the sweep's statistics words were zeroed by the cell-list build just enqueued (k_scan_tiles)
+    int fit_parity = 0;            // which of the two counts of fit_flag the next fit launch uses (the launch zeroes the other one)
+    void* fit_flag_seen = nullptr; // the fit_flag allocation (pointer and capacity) whose head has been zeroed
+    size_t fit_flag_cap_seen = 0;
+    bool stats_mirror_req = false; // pct_curvature: the fit about to be launched may mirror the sweep's statistics words
+    bool stats_mirrored = false;   // the fused fit copied the sweep's statistics words to pinned memory (no D2H copy needed)
     bool knn_valid = false;
     bool knn_sorted_space = false; // false: rows/ids are public indices (brute force)
     bool skip_dist_req = false;    // the caller will not read distances from the table (the fused curvature call)

@@ -2262,8 +2262,9 @@ int reserve_table(pct_ctx* ctx, int32_t k, double eps, bool with_dist = true) {
     if (with_dist) PCT_TRY(pct_reserve(ctx, &ctx->nbr_dist, rows * ctx->nbr_pitch * sizeof(float)));
     ctx->dist_valid = with_dist;
     if (eps > 0) PCT_TRY(pct_reserve(ctx, &ctx->nbr_cnt, rows * sizeof(int)));
-    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64 * sizeof(unsigned long long)));
+    if (!ctx->counters_clean) PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    ctx->counters_clean = false;
     return PCT_OK;
 }
 
@@ -2461,8 +2462,9 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
 }
 
 int pct_item_census(pct_ctx* ctx, int32_t k, unsigned long long out4[4]) {
-    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64));
+    PCT_TRY(pct_reserve(ctx, &ctx->counters, 64 * sizeof(unsigned long long)));
     PCT_HIP(ctx, hipMemsetAsync(ctx->counters.p, 0, 64, ctx->stream));
+    ctx->counters_clean = false;
     const int cap = k + 1 <= pct_fast_r1_max() ? kStageCap : PCT_STAGE_CAP2_HOST;
     const int blocks = (int)((ctx->n_items + 255) / 256 < 1024 ? (ctx->n_items + 255) / 256 : 1024);
     if (blocks > 0) {
