@@ -484,6 +484,16 @@ class Handle:
         self._lib.pct_get_timings(self._h, C.byref(t))
         return t.as_dict()
 
+    def stage_times(self):
+        """The same record as ``timings`` without building a dict: one struct kept on the handle, refilled and returned
+        (read ``.grid_ms``, ``.knn_ms``, ...).  For loops that poll after every step while the GPU waits for the host."""
+        t = self.__dict__.get("_tm")
+        if t is None:
+            t = self._tm = Timings()
+            self._tm_ref = C.byref(t)
+        self._lib.pct_get_timings(self._h, self._tm_ref)
+        return t
+
     # -- multi-GPU exchange (RCCL behind the C ABI) ---------------------------
     def comm_init(self, rank, world, unique_id):
         if len(unique_id) != 128:

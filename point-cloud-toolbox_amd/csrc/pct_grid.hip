@@ -131,8 +131,10 @@ struct PackAcc {
 
 // second stage of every packing pass: folds the per-block records into the handle's PackRed.  (Atomics from
 // every block onto one cache line cost more than the pass itself.)
+// carry = 0: nothing of the pass wrote the record directly (k_pack), so its previous content is not read and the
+// 128-byte memset in front of the pass -- a launch of its own -- is not needed.
 __global__ __launch_bounds__(kBlock) void k_pack_final(const PackRed* __restrict__ parts, int n_parts, PackRed* __restrict__ red,
-                                                       PackRed* __restrict__ host_copy) {
+                                                       PackRed* __restrict__ host_copy, int carry) {
     __shared__ PackRed sh[kBlock / 64];
     int bb[6] = {INT32_MAX, INT32_MAX, INT32_MAX, INT32_MIN, INT32_MIN, INT32_MIN};
     double s[3] = {0, 0, 0}, ss[3] = {0, 0, 0};
@@ -170,8 +172,8 @@ __global__ __launch_bounds__(kBlock) void k_pack_final(const PackRed* __restrict
     if (threadIdx.x == 0) {
         PackRed out = {};            // red was zeroed before the pass; bad / g_begin may have been set directly
         for (int a = 0; a < 3; ++a) { out.bb[a] = INT32_MAX; out.bb[3 + a] = INT32_MIN; }
-        out.bad = red->bad;
-        out.g_begin = red->g_begin;
+        out.bad = carry ? red->bad : 0;
+        out.g_begin = carry ? red->g_begin : 0;
         for (int i = 0; i < kBlock / 64; ++i) {
             for (int a = 0; a < 3; ++a) {
                 out.bb[a] = min(out.bb[a], sh[i].bb[a]);
@@ -734,23 +736,23 @@ int grid_1d(int64_t n, int per_block, int cap) {
 // ---------------------------------------------------------------------------
 static PackRed* red_parts(pct_ctx* ctx) { return (PackRed*)((char*)ctx->red.p + 128); }
 
-static int red_reset(pct_ctx* ctx, int n_parts) {
+static int red_reset(pct_ctx* ctx, int n_parts, bool zero = true) {
     PCT_TRY(pct_reserve(ctx, &ctx->red, 128 + (size_t)n_parts * sizeof(PackRed)));
-    PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 128, ctx->stream));
+    if (zero) PCT_HIP(ctx, hipMemsetAsync(ctx->red.p, 0, 128, ctx->stream));
     return PCT_OK;
 }
 
 // folds the n_parts block records of the pass just launched (the result also lands in pinned host memory)
-static int red_fold(pct_ctx* ctx, int n_parts) {
+static int red_fold(pct_ctx* ctx, int n_parts, bool carry = true) {
     PCT_LAUNCH(k_pack_final, dim3(1), dim3(kBlock), 0, ctx->stream, (const PackRed*)red_parts(ctx), n_parts,
-                       (PackRed*)ctx->red.p, (PackRed*)ctx->pin);
+                       (PackRed*)ctx->red.p, (PackRed*)ctx->pin, carry ? 1 : 0);
     PCT_HIP(ctx, hipGetLastError());
     return PCT_OK;
 }
 
 // ... and reads the result back
-static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox) {
-    PCT_TRY(red_fold(ctx, n_parts));
+static int red_read(pct_ctx* ctx, int n_parts, PackRed* out, float* bbox, bool carry = true) {
+    PCT_TRY(red_fold(ctx, n_parts, carry));
     PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
     memcpy(out, ctx->pin, sizeof(*out));
     for (int a = 0; a < 6; ++a) bbox[a] = order_float(out->bb[a]);
@@ -764,13 +766,13 @@ static int pack_all(pct_ctx* ctx, float* bbox, PackRed* red, bool defer = false)
     const int64_t n = ctx->n;
     PCT_TRY(pct_reserve(ctx, &ctx->pts4, (size_t)n * sizeof(float4)));
     const int nb = grid_1d(n, kBlock * 4, 512);
-    PCT_TRY(red_reset(ctx, nb));
+    PCT_TRY(red_reset(ctx, nb, false));
     PCT_LAUNCH(k_pack, dim3(nb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, (float4*)ctx->pts4.p, red_parts(ctx));
     PCT_HIP(ctx, hipGetLastError());
     if (defer) {
-        PCT_TRY(red_fold(ctx, nb));
+        PCT_TRY(red_fold(ctx, nb, false));
     } else {
-        PCT_TRY(red_read(ctx, nb, red, bbox));
+        PCT_TRY(red_read(ctx, nb, red, bbox, false));
         if (red->bad) return pct_fail(ctx, PCT_ERR_NONFINITE, "Non-finite values in input points");
     }
     ctx->pts4_valid = true;
