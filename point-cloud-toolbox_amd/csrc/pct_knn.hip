@@ -1228,16 +1228,23 @@ struct PairArgs {
     int shift_x, shift_xy;
     double eps2;
     pct_grid g;
+    // TREE (the hierarchical cell list, pct_tree.hip): an item is a run of queries of one segment; g = the finest level's grid
+    const int4* tree_seg;     // per segment {level, cx, cy, cz}
+    const int2* tree_runs;    // per segment 27 x {first position, points}, centre cell first
+    int tree_bits;
 };
 
 constexpr int kPairCap = kStageCap;
 static_assert((kPairCap & (kPairCap - 1)) == 0 && kPairCap % 128 == 0 && kPairCap <= 512, "staging capacity of k_knn_pair");
-struct PairLds {
-    float cx[kPairCap], cy[kPairCap], cz[kPairCap];      // staged stencil, 12 B per candidate
+static_assert(PCT_TREE_CAP % 128 == 0 && PCT_TREE_CAP <= 1024, "staging capacity of k_knn_pair on the hierarchical cell list");
+template <int CAP>
+struct PairLdsT {
+    float cx[CAP], cy[CAP], cz[CAP];                     // staged stencil, 12 B per candidate
     unsigned pend[64 + 4];                               // staged slots of the survivors of query a; [64]: the spare slot
     unsigned short pend_b[64 + 8];                       // ... of query b
     int offc[16];                                        // sorted position - flat slot, per non-empty run
 };
+using PairLds = PairLdsT<kPairCap>;
 
 #ifndef PCT_PAIR_WAVES
 #define PCT_PAIR_WAVES 1
@@ -1251,42 +1258,76 @@ constexpr int kPairWaves = PCT_PAIR_WAVES;
 // native float64 point (pct:83): the float32 pre-selection measures from the query ROUNDED to float32, a point
 // eq = |q64 - q32| away from the true one, and every bound taken from it moves by eq (see k_knn_fast); exact keys and
 // distances use the float64 query.
-template <bool EPS, bool DIST, bool Q64 = false>
-__global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(PairArgs a) {
-    constexpr int CAP = kPairCap, LIST = 64, SLOT_BITS = 6, KEY_BITS = 32 - SLOT_BITS;
-    __shared__ PairLds s_lds[kPairWaves];
+// TREE: the work items of the hierarchical cell list (round 3; k_knn_fast<1, .., TREE> until then) -- an item is a run of
+// queries of one octree segment, its stencil the 27 ranges of the Morton-ordered cloud the build recorded, its grid the
+// segment's level; 768 staged slots (what the build refines segments for), slot ids of 10 + 4 bits.
+template <bool EPS, bool DIST, bool Q64 = false, bool TREE = false>
+__global__ __launch_bounds__(64 * kPairWaves, (TREE ? 4 : Q64 ? 5 : 6)) void k_knn_pair(PairArgs a) {
+    constexpr int CAP = TREE ? PCT_TREE_CAP : kPairCap, LIST = 64, SLOT_BITS = 6, KEY_BITS = 32 - SLOT_BITS;
+    constexpr int SB = TREE ? 10 : 9;                    // bits of a staged slot inside a slot id (the run index sits above)
+    constexpr unsigned kIdMask = (1u << (SB + 4)) - 1u;
+    __shared__ PairLdsT<CAP> s_lds[kPairWaves];
     const int w = kPairWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = lane_id();
     const int blk = (int)blockIdx.x * kPairWaves + w;
     const int item = a.items_per_xcd ? (blk & 7) * a.items_per_xcd + (blk >> 3) : blk;
     if (item >= a.n_items || (a.items_per_xcd && (blk >> 3) >= a.items_per_xcd)) return;
-    PairLds& L = s_lds[w];
+    PairLdsT<CAP>& L = s_lds[w];
     const SortLanes sort_dir = make_sort_lanes();
     const int* __restrict__ cs = a.cell_start;
 
     const int2 it2 = a.items[item];
-    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
-    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
-    const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-    const int cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
-    const int rem = cell - cz * (nx * ny);
-    const int cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
-    const int cx = rem - cy * nx;
-    const int c0 = cs[cell];
-    const int qs = c0 + chunk * a.items_q;                        // owned points sit first in the cell
-    const int nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
-    const int row0 = a.own_start[cell] + chunk * a.items_q;       // neighbour-table row of query qs
-
-    // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+    constexpr int NRUNS = TREE ? 27 : 9;                          // ranges of the cloud the stencil is staged from
+    int cx, cy, cz, qs, nq, row0;
     int run_s = 0, run_len = 0;
-    if (lane < 9) {
-        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
-        if (z >= 0 && z < nz && y >= 0 && y < ny) {
-            const int row = (z * ny + y) * nx;
-            run_s = cs[row + max(cx - 1, 0)];
-            run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+    pct_grid g_lvl;                                               // TREE: the grid of the item's level
+    if constexpr (TREE) {
+        // item = {first query (Morton position = table row) | (queries - 1) << 26, segment}
+        const int seg = __builtin_amdgcn_readfirstlane(it2.y);
+        if (seg < 0) return;                                      // an item of a segment that was split (k_tree_refine)
+        const unsigned packed = (unsigned)__builtin_amdgcn_readfirstlane(it2.x);
+        qs = (int)(packed & 0x3ffffffu);
+        nq = (int)(packed >> 26) + 1;
+        row0 = qs;
+        const int4 hd = a.tree_seg[seg];
+        const int level = __builtin_amdgcn_readfirstlane(hd.x);
+        cx = __builtin_amdgcn_readfirstlane(hd.y);
+        cy = __builtin_amdgcn_readfirstlane(hd.z);
+        cz = __builtin_amdgcn_readfirstlane(hd.w);
+        // edges scale by exact powers of two, so (x - o) * inv_cell - cx lies in [0, 1) for every point of the cell
+        g_lvl = a.g;
+        g_lvl.cell = __builtin_ldexp(a.g.cell, level);
+        g_lvl.inv_cell = __builtin_ldexp(a.g.inv_cell, -level);
+        g_lvl.nx = g_lvl.ny = g_lvl.nz = 1 << (a.tree_bits - level);
+        if (lane < 27) {
+            const int2 r = a.tree_runs[(int64_t)seg * 27 + lane];
+            run_s = r.x;
+            run_len = r.y;
+        }
+    } else {
+        const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+        const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+        const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+        cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
+        const int rem = cell - cz * (nx * ny);
+        cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
+        cx = rem - cy * nx;
+        const int c0 = cs[cell];
+        qs = c0 + chunk * a.items_q;                              // owned points sit first in the cell
+        nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
+        row0 = a.own_start[cell] + chunk * a.items_q;             // neighbour-table row of query qs
+
+        // ---- bounds of the 9 x-runs of the 27-cell stencil, fetched in parallel by lanes 0..8 (centre row first)
+        if (lane < 9) {
+            const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+            if (z >= 0 && z < nz && y >= 0 && y < ny) {
+                const int row = (z * ny + y) * nx;
+                run_s = cs[row + max(cx - 1, 0)];
+                run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+            }
         }
     }
+    const pct_grid& G = TREE ? g_lvl : a.g;
     // the item's own queries (<= items_q <= 64 consecutive sorted positions), one per lane
     float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
     double my_qx = 0., my_qy = 0., my_qz = 0.;
@@ -1308,13 +1349,16 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
     {
         int acc = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NRUNS; ++t) {
             my_pre = lane == t ? acc : my_pre;
             acc += __builtin_amdgcn_readlane(run_len, t);
         }
         m = acc;
     }
-    if (m > CAP) {
+    // (tree items: four bits of run index per slot id, 16 non-empty ranges -- a surface meets about ten of its 27 stencil
+    // cells; more is a volume, where these items pay as little as uniform cells do)
+    const bool crowded = TREE && __popcll(__builtin_amdgcn_ballot_w64(lane < NRUNS && run_len > 0)) > 16;
+    if (m > CAP || crowded) {
         // stencil does not fit the staging area (dense cluster): the exact sweep takes the whole item
         int base = 0;
         if (lane == 0) base = atomicAdd(a.redo_count, nq);
@@ -1335,7 +1379,7 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
         unsigned* bits = L.pend;
         if (lane < CAP / 32) bits[lane] = 0u;
         wave_lds_sync();
-        const bool nonempty = lane < 9 && run_len > 0;
+        const bool nonempty = lane < NRUNS && run_len > 0;
         const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
         if (nonempty) {
             atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
@@ -1357,7 +1401,7 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
                 const int u = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(S >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)S, (unsigned)s0));
                 ubase += (int)__popcll(B);
                 const int j = b * 64 + lane;
-                slotx[b] |= (unsigned)u << 9;
+                slotx[b] |= (unsigned)u << SB;
                 if (j < m) tmp[b] = a.pts[j + L.offc[u]];
             }
         }
@@ -1377,16 +1421,16 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
     const int k = a.k;
     const double eps2 = EPS ? a.eps2 : (double)INFINITY;
     constexpr double kKeyRange = 2.3;                     // what the 27-cell cube can vouch for, in cell^2 (k_knn_fast)
-    const double edge = a.g.cell;
+    const double edge = G.cell;
     const double scale = (double)(1u << KEY_BITS) / (kKeyRange * edge * edge);
     constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
     unsigned my_gkey;                                     // per query (lane l = query l): the largest key the stencil vouches for
     {
         const double lqx = Q64 ? my_qx : (double)my_q.x, lqy = Q64 ? my_qy : (double)my_q.y, lqz = Q64 ? my_qz : (double)my_q.z;
-        const double gx = (lqx - a.g.ox) * a.g.inv_cell - cx;
-        const double gy = (lqy - a.g.oy) * a.g.inv_cell - cy;
-        const double gz = (lqz - a.g.oz) * a.g.inv_cell - cz;
-        const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
+        const double gx = (lqx - G.ox) * G.inv_cell - cx;
+        const double gy = (lqy - G.oy) * G.inv_cell - cy;
+        const double gz = (lqz - G.oz) * G.inv_cell - cz;
+        const double g2 = fmin(guaranteed_r2(G, cx, cy, cz, gx, gy, gz, 1), limit_r2(G, cx, cy, cz, gx, gy, gz));
         my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
@@ -1404,7 +1448,8 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
     const bool col_lane = lane >= 1 && lane <= k;         // lanes whose list entry is a table column
     const unsigned long long first_k1 = (2ull << k) - 1ull;          // lanes 0 .. k: the entries whose order matters
 
-    static_assert(CAP == 512, "slot ids: 9 bits of slot, 4 bits of run index");
+    static_assert(CAP <= (1 << SB) && SB + 4 <= 16, "slot ids: SB bits of slot, 4 bits of run index, 16-bit survivor list of query b");
+    const auto slot_of = [](unsigned id) { return TREE ? min((int)(id & ((1u << SB) - 1u)), CAP - 1) : (int)(id & (unsigned)(CAP - 1)); };
 
     const auto pair_loop = [&](auto NBP_) {
         constexpr int NBP = decltype(NBP_)::value, NBU = 2 * NBP;
@@ -1580,9 +1625,9 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
             // ---- exact keys for the survivors only.  Survivor `lane` of each query: staged slot -> coordinates -> fp64
             // ((dx^2 + dy^2) + dz^2) (no FMA: SciPy's value) -> key, distance, sorted position; worked out by every lane
             // (a stale list entry is masked into the staging area and gives a garbage value nobody uses).
-            const unsigned sxa = L.pend[lane] & 0x1FFFu, sxb = (unsigned)L.pend_b[lane] & 0x1FFFu;      // slot | run << 9
-            const int ja = (int)(sxa & (CAP - 1)), jb = (int)(sxb & (CAP - 1));
-            const int out_pa = ja + L.offc[sxa >> 9], out_pb = jb + L.offc[sxb >> 9];                   // sorted positions
+            const unsigned sxa = L.pend[lane] & kIdMask, sxb = (unsigned)L.pend_b[lane] & kIdMask;      // slot | run << SB
+            const int ja = slot_of(sxa), jb = slot_of(sxb);
+            const int out_pa = ja + L.offc[sxa >> SB], out_pb = jb + L.offc[sxb >> SB];                 // sorted positions
             float out_da = 0.f, out_db = 0.f;
             unsigned e_a, e_b;
 #ifdef PCT_ABL_NO_KEYS
@@ -1644,7 +1689,7 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
                         const double ux = qax, uy = qay, uz = qaz;
                         const bool done = order_equal_keys<1, SLOT_BITS>(&e_a, a.pts,
                             [&](unsigned at) {
-                                const int j = (int)L.pend[at] & (CAP - 1);
+                                const int j = slot_of(L.pend[at]);
                                 const double dx = (double)L.cx[j] - ux, dy = (double)L.cy[j] - uy, dz = (double)L.cz[j] - uz;
                                 return (dx * dx + dy * dy) + dz * dz;
                             },
@@ -1655,7 +1700,7 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
                         const double ux = qbx, uy = qby, uz = qbz;
                         const bool done = order_equal_keys<1, SLOT_BITS>(&e_b, a.pts,
                             [&](unsigned at) {
-                                const int j = (int)L.pend_b[at] & (CAP - 1);
+                                const int j = slot_of((unsigned)L.pend_b[at]);
                                 const double dx = (double)L.cx[j] - ux, dy = (double)L.cy[j] - uy, dz = (double)L.cz[j] - uz;
                                 return (dx * dx + dy * dy) + dz * dz;
                             },
@@ -1706,7 +1751,9 @@ __global__ __launch_bounds__(64 * kPairWaves, (Q64 ? 5 : 6)) void k_knn_pair(Pai
         if (nbp <= 1) pair_loop(integral_constant<int, 1>{});
         else if (nbp == 2) pair_loop(integral_constant<int, 2>{});
         else if (nbp == 3) pair_loop(integral_constant<int, (CAP >= 384 ? 3 : 1)>{});
-        else pair_loop(integral_constant<int, (CAP >= 512 ? 4 : 1)>{});
+        else if (nbp == 4) pair_loop(integral_constant<int, (CAP >= 512 ? 4 : 1)>{});
+        else if (nbp == 5) pair_loop(integral_constant<int, (CAP >= 640 ? 5 : 1)>{});
+        else pair_loop(integral_constant<int, (CAP >= 768 ? 6 : 1)>{});
     }
 #if defined(PCT_ABL_NO_SORT) || defined(PCT_ABL_NO_COMPACT) || defined(PCT_ABL_NO_KEYS) || defined(PCT_ABL_NO_TRIAL) || defined(PCT_ABL_NO_STORE) || defined(PCT_ABL_NO_CHECK)
     redo_mask = 0ull;          // timing experiments: nothing goes to the exact sweep
@@ -2415,9 +2462,15 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
     if (ctx->level_mode || ctx->own_flag || ctx->q_begin != 0 || ctx->q_end != ctx->n)
         return pct_fail(ctx, PCT_ERR_INVALID, "the tree sweep takes whole clouds");
     const int64_t n_rows = ctx->n;
-    PCT_TRY(reserve_table(ctx, k, eps));
+    // one list register: the scalar-lean kernel's TREE instantiation (k_knn_pair); it can leave the distance table out
+    // for the fused call, like the uniform list's
+    const bool pair_tree = k + 1 <= pct_fast_r1_max() && ctx->n_items > 0 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
+                           !pct_getenv("PCT_NO_PAIR") && !pct_getenv("PCT_NO_PAIR_KERNEL") && !pct_getenv("PCT_TREE_EXACT_ONLY");
+    const bool skip_dist = pair_tree && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
+    PCT_TRY(reserve_table(ctx, k, eps, !skip_dist));
     PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
     KnnArgs a = make_args(ctx, k, eps, true);
+    if (!ctx->dist_valid) a.nbr_dist = nullptr;
     a.tree_seg = (const int4*)ctx->tree_seg.p;
     a.tree_runs = (const int2*)ctx->tree_runs.p;
     a.tree_bits = ctx->tree_bits;
@@ -2437,6 +2490,30 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
         // (Q64); where that distance is not small against the item's cells the proofs fail and the exact sweep answers
 #define PCT_TREE(R_, E_, Q_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, true, true, Q_, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
+        if (pair_tree) {
+            PairArgs pa = {};
+            pa.pts = a.pts; pa.ptsd = a.ptsd; pa.cell_start = a.cell_start;
+            pa.items = items;
+            pa.nbr_pos = a.nbr_pos; pa.nbr_dist = a.nbr_dist; pa.nbr_cnt = a.nbr_cnt;
+            pa.redo = redo; pa.redo_count = redo_count; pa.counters = a.counters;
+            pa.n_items = (int)ctx->n_items; pa.items_q = ctx->items_q;
+            pa.k = a.k; pa.pitch = a.pitch; pa.stats = a.stats; pa.eps2 = a.eps2; pa.g = a.g;
+            pa.tree_seg = a.tree_seg; pa.tree_runs = a.tree_runs; pa.tree_bits = a.tree_bits;
+            pa.items_per_xcd = pct_getenv("PCT_NO_XCD_MAP") ? 0 : (int)((ctx->n_items + 7) / 8);
+            const int64_t n_blk = pa.items_per_xcd ? (int64_t)pa.items_per_xcd * 8 : ctx->n_items;
+            const dim3 gridp((unsigned)((n_blk + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
+#define PCT_PAIR_TREE(E_, D_, Q_) PCT_LAUNCH((k_knn_pair<E_, D_, Q_, true>), gridp, blockp, 0, ctx->stream, pa)
+            if (ctx->has_f64) {
+                if (e && skip_dist) PCT_PAIR_TREE(true, false, true);
+                else if (e) PCT_PAIR_TREE(true, true, true);
+                else if (skip_dist) PCT_PAIR_TREE(false, false, true);
+                else PCT_PAIR_TREE(false, true, true);
+            } else if (e && skip_dist) PCT_PAIR_TREE(true, false, false);
+            else if (e) PCT_PAIR_TREE(true, true, false);
+            else if (skip_dist) PCT_PAIR_TREE(false, false, false);
+            else PCT_PAIR_TREE(false, true, false);
+#undef PCT_PAIR_TREE
+        } else
         if (ctx->has_f64) {
             if (r1 && !e) PCT_TREE(1, false, true, grid1, block1);
             else if (r1) PCT_TREE(1, true, true, grid1, block1);
