@@ -1182,6 +1182,11 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_LAUNCH(k_scan_tiles, dim3(1), dim3(1024), 0, ctx->stream, (int4*)ctx->scan_tmp.p, nblk,
                            (const unsigned long long*)sq_part, (ScanTotals*)(ctx->pin + 128), (unsigned long long*)ctx->counters.p);
         ctx->counters_clean = true;
+        // the totals this pass is judged by (and, with a deferred pack, the cloud's box) are in pinned memory from here on:
+        // the host waits for THIS point, not for the end of the stream -- while it wakes up, decides and enqueues the
+        // sweep, the device applies the scan and scatters the records (50 us at 1 M points; the read-back used to be ~25
+        // us of an idle device).  A pass that is rejected has scattered for nothing, as before.
+        PCT_HIP(ctx, hipEventRecord(ctx->ev[8], ctx->stream));
         PCT_LAUNCH(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
@@ -1192,7 +1197,7 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
                            ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr,
                            ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
         PCT_HIP(ctx, hipGetLastError());
-        PCT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PCT_HIP(ctx, hipEventSynchronize(ctx->ev[8]));
         if (spec) {                      // the deferred pack result is in: was the old box still right?
             spec = false;
             memcpy(&red, ctx->pin, sizeof(red));

@@ -53,7 +53,7 @@ struct pct_ctx {
     int device = 0;
     pct_comm* comm = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[8] = {};
+    hipEvent_t ev[9] = {};         // [0..7] stage timings; [8]: the cell list's scan totals are in pinned memory (pct_build_grid)
     char err[512] = {0};
 
     int64_t n = 0;                 // cloud size (candidates)
