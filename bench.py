@@ -335,6 +335,11 @@ def main():
     ownership = args.ownership if args.ownership != "auto" else ("slab" if args.config == "c4" else "range")
     if not dist_mode:
         handle.set_points(local)                              # resident before the timed region
+        # A stream of clouds: the call returns once its kernels are enqueued, the host prepares the next step under the fit
+        # of this one (pct_set_async; every getter and handle.synchronize() wait for the pending call).  The timed region
+        # ends with a barrier that waits for everything; PCT_BENCH_SYNC_STEPS=1 runs the blocking calls instead.
+        async_steps = os.environ.get("PCT_BENCH_SYNC_STEPS") != "1"
+        handle.set_async(async_steps)
 
         def step():
             handle.curvature(k, eps, _capi.KNN_GRID)
@@ -360,8 +365,8 @@ def main():
         a_knn = a_fit = a_grid = a_fast = 0.0
         for _ in range(steps):
             step()
-            tm = handle.stage_times()                         # hipEvent times recorded on the handle's stream (one reused struct:
-            a_knn += tm.knn_ms                                # the GPU idles while the host is between two steps)
+            tm = handle.stage_times_done()                    # hipEvent times of the last FINISHED step (asynchronous steps: the
+            a_knn += tm.knn_ms                                # one before the step just enqueued), one reused struct
             a_fit += tm.fit_ms
             a_grid += tm.grid_ms
             a_fast += tm.knn_fast_ms
@@ -510,6 +515,8 @@ def main():
             "stage_ms": {"grid_build": acc["grid_ms"] / steps, "knn": acc["knn_ms"] / steps, "knn_fast_kernel": fast_ms / steps,
                          "fit_curvature": acc["fit_ms"] / steps},
             "repeat_ms_per_step": repeats,
+            "calls": ("asynchronous (pct_set_async): a step returns once its kernels are enqueued, the timed region ends with a wait for "
+                      "everything; PCT_BENCH_SYNC_STEPS=1 for blocking calls") if (not dist_mode and async_steps) else "blocking",
             "clock_ramp": {"ms": ramp_ms, "steps": ramp_steps,
                            "what": "untimed runs of the same step before the W warm-up steps, so that the timed region starts at working clocks"},
             "grid_points_per_rank": last_tm["grid_points"],

@@ -272,6 +272,14 @@ int pct_comm_allreduce_f64(pct_ctx* ctx, double* values, int32_t n, int32_t op);
 
 /* ---- measurement -------------------------------------------------------- */
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out);
+/* Streams of clouds.  With pct_set_async(ctx, 1) a pct_curvature call on a whole-cloud handle (no query range or slab,
+ * statistics off) returns as soon as its kernels are enqueued: the host uploads and enqueues cloud i + 1 while the device
+ * still fits cloud i.  Every other entry point (getters, pct_synchronize, pct_get_timings, a new cloud ...) first waits
+ * for the pending call, so results are never observed early; an error of the pending call's kernels is reported by the
+ * call that waits.  pct_get_timings_done does NOT wait: it returns the timings of the most recent call whose kernels are
+ * known to have finished (the call before the pending one) -- what a loop polls after every step.  Off by default. */
+int pct_set_async(pct_ctx* ctx, int32_t enable);
+int pct_get_timings_done(const pct_ctx* ctx, pct_timings* out);
 /* sizeof(pct_timings) as the library was built: a binding checks its own struct against it at load time. */
 int pct_timings_size(void);
 /* Device pointer helpers for zero-copy interop (multi-GPU all-gather target). */

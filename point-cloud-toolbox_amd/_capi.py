@@ -69,6 +69,8 @@ SIGNATURES = {
     "pct_slab_records": (C.c_int, [_p, _p, C.c_int64, C.POINTER(C.c_int64)]),
     "pct_scatter_records": (C.c_int, [_p, _p, C.c_int64, C.c_int64, C.c_int64, _p, _p]),
     "pct_set_grid_param": (C.c_int, [_p, C.c_double]),
+    "pct_set_async": (C.c_int, [_p, C.c_int32]),
+    "pct_get_timings_done": (C.c_int, [_p, C.POINTER(Timings)]),
     "pct_set_stats": (C.c_int, [_p, C.c_int32]),
     "pct_knn": (C.c_int, [_p, C.c_int32, C.c_double, C.c_int32]),
     "pct_get_neighbors": (C.c_int, [_p, C.c_int64, C.c_int64, _i32p, _f32p, _i32p]),
@@ -483,6 +485,21 @@ class Handle:
         t = Timings()
         self._lib.pct_get_timings(self._h, C.byref(t))
         return t.as_dict()
+
+    def set_async(self, enable=True):
+        """Streams of clouds: ``curvature`` on a whole-cloud handle returns once its kernels are enqueued; every other
+        call first waits for it (include/pct_hip.h, pct_set_async)."""
+        self._check(self._lib.pct_set_async(self._h, int(bool(enable))))
+
+    def stage_times_done(self):
+        """Timings of the most recent call whose kernels are known to have finished -- with ``set_async`` the call before
+        the pending one; does not wait.  One struct kept on the handle, refilled and returned."""
+        t = self.__dict__.get("_tm")
+        if t is None:
+            t = self._tm = Timings()
+            self._tm_ref = C.byref(t)
+        self._lib.pct_get_timings_done(self._h, self._tm_ref)
+        return t
 
     def stage_times(self):
         """The same record as ``timings`` without building a dict: one struct kept on the handle, refilled and returned

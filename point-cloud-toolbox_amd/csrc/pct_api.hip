@@ -67,10 +67,49 @@ int pct_reserve(pct_ctx* ctx, pct_buf* b, size_t bytes) {
 
 static void release(pct_buf* b) { pct_release(b); }
 
-static float ev_ms(pct_ctx* ctx, int a, int b) {
+static float ev_ms(const hipEvent_t* ev, int a, int b) {
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, ctx->ev[a], ctx->ev[b]) != hipSuccess) ms = 0.f;
+    if (hipEventElapsedTime(&ms, ev[a], ev[b]) != hipSuccess) ms = 0.f;
     return ms;
+}
+static float ev_ms(pct_ctx* ctx, int a, int b) { return ev_ms(ctx->ev, a, b); }
+
+// pinned words the kernels of a fused call write for the host: sweep statistics (8 x u64) and the SVD row count, one set
+// per parity of the call (pct_set_async: the next call's kernels must not overwrite what the pending one's left)
+static unsigned long long* stat_slot(pct_ctx* ctx, int par) { return (unsigned long long*)(ctx->pin + (par ? 256 : 192)); }
+static long long* svd_slot(pct_ctx* ctx, int par) { return (long long*)(ctx->pin + 2048 + 8 * par); }
+
+// bookkeeping of the pending fused call, whose kernels have finished: timings from its event set, statistics, the
+// uneven-density verdict for the next sweep
+static void finish_pending(pct_ctx* ctx, const hipEvent_t* ev) {
+    pct_timings t = ctx->tm_snap;
+    const unsigned long long* c = stat_slot(ctx, ctx->pend_par);
+    t.ring_fallbacks = (int64_t)c[0];
+    t.lds_overflows = (int64_t)c[1];
+    t.flushes = (int64_t)c[2];
+    t.candidate_steps = (int64_t)c[3];
+    t.redone_queries = (int64_t)c[4];
+    t.grid_ms = ev_ms(ev, 2, 3);
+    t.knn_ms = ev_ms(ev, 3, 4);
+    t.knn_fast_ms = ctx->pend_sorted ? ev_ms(ev, 3, 7) : 0.f;
+    t.fit_ms = ev_ms(ev, 5, 6);
+    t.total_ms = ev_ms(ev, 2, 6);
+    t.fit_svd_rows = *svd_slot(ctx, ctx->pend_par);
+    const int64_t redone = (int64_t)(unsigned)(c[7] & 0xFFFFFFFFull);
+    if (ctx->pend_sorted && !ctx->pend_levels) ctx->uneven = redone * 20 > ctx->pend_owned && ctx->pend_owned >= 65536;
+    else if (ctx->pend_levels && t.levels <= 1) ctx->uneven = false;
+    ctx->tm_done = t;
+    ctx->pending = false;
+}
+
+// every entry point but an asynchronous pct_curvature: wait for the pending call and do its bookkeeping first
+static int drain(pct_ctx* ctx) {
+    if (!ctx->pending) return PCT_OK;
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    finish_pending(ctx, ctx->ev);
+    ctx->tm = ctx->tm_done;
+    PCT_HIP(ctx, e);
+    return PCT_OK;
 }
 
 extern "C" {
@@ -163,6 +202,11 @@ int pct_create(int device, pct_ctx** out) {
             delete ctx;
             return PCT_ERR_HIP;
         }
+    for (int i = 2; i <= 7; ++i)               // the second set of timing events (pct_set_async)
+        if (hipEventCreate(&ctx->ev_prev[i]) != hipSuccess) {
+            delete ctx;
+            return PCT_ERR_HIP;
+        }
     if (hipHostMalloc((void**)&ctx->pin, 4096, hipHostMallocMapped) != hipSuccess) {
         delete ctx;
         return PCT_ERR_OOM;
@@ -186,16 +230,19 @@ void pct_destroy(pct_ctx* ctx) {
     if (ctx->pin) (void)hipHostFree(ctx->pin);
     for (auto& e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto& e : ctx->ev_prev)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
 const char* pct_last_error(const pct_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
-static int begin_call(pct_ctx* ctx) {
+static int begin_call(pct_ctx* ctx, bool wait_for_pending = true) {
     if (!ctx) return PCT_ERR_INVALID;
     ctx->err[0] = 0;
     PCT_HIP(ctx, hipSetDevice(ctx->device));
+    if (wait_for_pending) PCT_TRY(drain(ctx));
     return PCT_OK;
 }
 
@@ -537,7 +584,7 @@ static int run_knn(pct_ctx* ctx, int32_t k, double eps, int32_t algo, bool fuse_
 }
 
 static int finish_knn_stats(pct_ctx* ctx, bool* beyond_limits) {
-    unsigned long long* c = (unsigned long long*)(ctx->pin + 192);       // pinned: a plain DMA, no staging
+    unsigned long long* c = stat_slot(ctx, 0);                           // pinned: a plain DMA, no staging
     // (the fused call's fit kernel has already written them there: one launch less in the step's tail)
     if (!ctx->stats_mirrored)
         PCT_HIP(ctx, hipMemcpyAsync(c, ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));   // [7] low word: rows on the redo list
@@ -598,8 +645,73 @@ int pct_fit(pct_ctx* ctx) {
     return PCT_OK;
 }
 
-int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+int pct_set_async(pct_ctx* ctx, int32_t enable) {
     PCT_TRY(begin_call(ctx));
+    ctx->async_mode = enable != 0;
+    return PCT_OK;
+}
+
+// pct_curvature of a stream of clouds (pct_set_async): enqueue and return.  The previous call's bookkeeping is done here,
+// after the cell list's mid-build wait -- which lies behind all of that call's kernels on the stream --, without a wait
+// of its own.
+static int curvature_async(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+    const bool had = ctx->pending;
+    if (had)          // the pending call keeps its timing events; this one records into the other set
+        for (int i = 2; i <= 7; ++i) { hipEvent_t t = ctx->ev[i]; ctx->ev[i] = ctx->ev_prev[i]; ctx->ev_prev[i] = t; }
+    const int par = had ? ctx->pend_par ^ 1 : 0;
+    ctx->retries = 0;
+    ctx->fit_par = par;            // (also for the fits a chained sweep launches itself)
+    int st = run_knn(ctx, k, eps, algo, true);
+    if (st == PCT_OK) {
+        st = [&]() -> int {
+            PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+            ctx->stats_mirrored = false;
+            ctx->stats_mirror_req = true;
+            const int fs = pct_launch_fit_table(ctx);
+            ctx->stats_mirror_req = false;
+            PCT_TRY(fs);
+            PCT_HIP(ctx, hipEventRecord(ctx->ev[6], ctx->stream));
+            if (!ctx->stats_mirrored)     // (no fit kernel ran: the chained sweep fitted its passes itself, or there are no rows)
+                PCT_HIP(ctx, hipMemcpyAsync(stat_slot(ctx, par), ctx->counters.p, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->stats_mirrored = false;
+            return PCT_OK;
+        }();
+    }
+    ctx->fit_par = 0;
+    if (st != PCT_OK) {            // leave the handle in the plain state: nothing pending, events where they were
+        (void)hipStreamSynchronize(ctx->stream);
+        if (had) {
+            for (int i = 2; i <= 7; ++i) { hipEvent_t t = ctx->ev[i]; ctx->ev[i] = ctx->ev_prev[i]; ctx->ev_prev[i] = t; }
+            finish_pending(ctx, ctx->ev);
+        }
+        return st;
+    }
+    if (had) {
+        // its kernels lie in front of this call's mid-build wait on the stream: normally long finished (checked, not assumed)
+        if (hipEventQuery(ctx->ev_prev[6]) != hipSuccess) (void)hipEventSynchronize(ctx->ev_prev[6]);
+        (void)hipGetLastError();
+        finish_pending(ctx, ctx->ev_prev);
+    }
+    ctx->tm.limit_retries = 0;
+    ctx->tm_snap = ctx->tm;
+    ctx->pend_par = par;
+    ctx->pend_sorted = ctx->knn_sorted_space;
+    ctx->pend_levels = ctx->last_levels;
+    ctx->pend_owned = ctx->q_end - ctx->q_begin;
+    ctx->pending = true;
+    ctx->fit_rows = ctx->q_end - ctx->q_begin;
+    ctx->fit_valid = true;
+    ctx->fit_cloud_aligned = true;
+    return PCT_OK;
+}
+
+int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
+    // (asynchronous only where nothing of the sweep's verdict is needed before returning: a whole-cloud handle never
+    // repeats a pass for points it left out, and statistics are off)
+    const bool async = ctx && ctx->async_mode && ctx->n > 0 && ctx->q_begin == 0 && ctx->q_end == ctx->n && ctx->slab_parts == 0 &&
+                       !ctx->collect_stats;
+    PCT_TRY(begin_call(ctx, !async));
+    if (async) return curvature_async(ctx, k, eps, algo);
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool again = false;
         PCT_TRY(run_knn(ctx, k, eps, algo, true));
@@ -616,8 +728,9 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
     }
     ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
-    ctx->tm.fit_svd_rows = *(const long long*)(ctx->pin + 2048);
+    ctx->tm.fit_svd_rows = *svd_slot(ctx, 0);
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
+    ctx->tm_done = ctx->tm;
     ctx->fit_rows = ctx->q_end - ctx->q_begin;
     ctx->fit_valid = true;
     ctx->fit_cloud_aligned = true;
@@ -983,7 +1096,17 @@ int pct_timings_size(void) { return (int)sizeof(pct_timings); }
 
 int pct_get_timings(const pct_ctx* ctx, pct_timings* out) {
     if (!ctx || !out) return PCT_ERR_INVALID;
+    if (ctx->pending) {                    // (an asynchronous call: its times exist once its kernels have finished)
+        pct_ctx* c = const_cast<pct_ctx*>(ctx);
+        PCT_TRY(begin_call(c));
+    }
     *out = ctx->tm;
+    return PCT_OK;
+}
+
+int pct_get_timings_done(const pct_ctx* ctx, pct_timings* out) {
+    if (!ctx || !out) return PCT_ERR_INVALID;
+    *out = ctx->pending ? ctx->tm_done : ctx->tm;
     return PCT_OK;
 }
 

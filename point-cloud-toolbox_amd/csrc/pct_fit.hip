@@ -739,7 +739,7 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     a.stat_dst = nullptr;
     if (ctx->stats_mirror_req && ctx->counters.p) {
         a.stat_src = (const unsigned long long*)ctx->counters.p;
-        a.stat_dst = (unsigned long long*)(ctx->pin + 192);
+        a.stat_dst = (unsigned long long*)(ctx->pin + (ctx->fit_par ? 256 : 192));
         ctx->stats_mirrored = true;
     }
     ctx->stats_mirror_req = false;
@@ -762,7 +762,7 @@ int launch(pct_ctx* ctx, const FitArgs& a0, bool f64) {
     PCT_HIP(ctx, hipGetLastError());
     // the rows handed over: fixed grid, the list length is read on the device
     const int sblocks = blocks < 1024 ? blocks : 1024;
-    long long* note = (long long*)(ctx->pin + 2048);
+    long long* note = (long long*)(ctx->pin + 2048 + 8 * ctx->fit_par);
     if (a.coefs64) {
         if (f64)
             PCT_LAUNCH((k_fit_svd<true, true>), dim3(sblocks), dim3(64), 0, ctx->stream, a, a.flag_list, a.flag_count, note);

@@ -54,6 +54,19 @@ struct pct_ctx {
     pct_comm* comm = nullptr;
     hipStream_t stream = nullptr;
     hipEvent_t ev[9] = {};         // [0..7] stage timings; [8]: the cell list's scan totals are in pinned memory (pct_build_grid)
+    // Streams of clouds (pct_set_async): a fused call returns once its kernels are enqueued; its timing events, its
+    // statistics words and its SVD row count wait in the set of the call's parity until the NEXT fused call has passed
+    // its mid-build wait (everything of the previous call has completed by then) or until anything else is asked of the
+    // handle (which first waits for the stream).  The host prepares step i + 1 while the device fits step i.
+    hipEvent_t ev_prev[9] = {};    // the timing events of the pending call while a new one records into ev
+    bool async_mode = false;
+    bool pending = false;          // a fused call has been enqueued and its bookkeeping has not been done
+    int pend_par = 0;              // parity of the pending call: which pinned slots its kernels write
+    bool pend_sorted = false, pend_levels = false;
+    int64_t pend_owned = 0;
+    int fit_par = 0;               // which pinned slots (statistics mirror, SVD row count) the fits being launched write
+    pct_timings tm_snap = {};      // the host-side fields of the pending call's timings
+    pct_timings tm_done = {};      // timings of the last call whose bookkeeping has been done
     char err[512] = {0};
 
     int64_t n = 0;                 // cloud size (candidates)

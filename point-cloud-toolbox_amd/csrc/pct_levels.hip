@@ -186,7 +186,7 @@ void swap_buf(T& a, T& b) { T t = a; a = b; b = t; }
 }  // namespace
 
 int pct_knn_levels(pct_ctx* ctx, int32_t k, double eps) {
-    *(long long*)(ctx->pin + 2048) = 0;        // rows the passes' fits hand to k_fit_svd: summed over the passes of this call
+    *(long long*)(ctx->pin + 2048 + 8 * ctx->fit_par) = 0;        // rows the passes' fits hand to k_fit_svd: summed over the passes of this call
     const int64_t nq = ctx->q_end - ctx->q_begin;
     if (ctx->n >= ((int64_t)1 << 29)) return pct_fail(ctx, PCT_ERR_INVALID, "the chained sweep handles clouds below 2^29 points");
     const int pitch = (k + 3) & ~3;

@@ -1614,6 +1614,67 @@ def test_random_cross_check(gpu):
     assert done >= 50
 
 
+def test_asynchronous_calls_of_a_stream_of_clouds(gpu):
+    """pct_set_async: pct_curvature on a whole-cloud handle returns once its kernels are enqueued; the next call does the
+    previous one's bookkeeping after its own mid-build wait, any other entry point waits first.  Same values as the plain
+    handle, timings of every call, through the uniform list, the hierarchical list, the chained sweep, with eps, with two
+    list registers; an error leaves the handle usable; a sharded handle and a handle with statistics stay synchronous."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    rng = np.random.default_rng(77)
+    even = shapes.torus_random(120_000, seed=3)
+    r = 10.0 ** rng.uniform(-2.0, 0.0, size=150_000)                     # density ~ 1/r^2: AUTO takes the hierarchical list
+    th = rng.uniform(0, 2 * np.pi, size=len(r))
+    scan = np.stack([r * np.cos(th), r * np.sin(th), 0.02 * np.sin(8 * r)], 1).astype(np.float32)
+    ref, h = capi.Handle(0), capi.Handle(0)
+    h.set_async(True)
+    for pts, k, eps, algo in ((even, 50, 0.0, capi.KNN_GRID), (even, 50, 0.0, capi.KNN_AUTO), (even, 80, 0.0, capi.KNN_GRID),
+                              (even, 30, 0.03, capi.KNN_GRID), (scan, 40, 0.0, capi.KNN_AUTO), (scan, 40, 0.0, capi.KNN_GRID_LEVELS),
+                              (scan, 40, 0.0, capi.KNN_TREE), (even.astype(np.float64), 50, 0.0, capi.KNN_GRID)):
+        ref.set_points(pts)
+        ref.curvature(k, eps, algo)
+        c0, K0, H0, _ = ref.get_fit(0, len(pts))
+        t_ref = ref.timings()
+        h.set_points(pts)
+        for step in range(4):                                           # back to back: each call finishes the one before it
+            h.curvature(k, eps, algo)
+            t = h.stage_times_done()
+            if step >= 1:
+                assert t.knn_ms > 0 and t.fit_ms >= 0 and t.total_ms >= t.knn_ms, (step, t.as_dict())
+                assert t.algo == t_ref["algo"] and t.grid_points == t_ref["grid_points"]
+        c, K, H, _ = h.get_fit(0, len(pts))                              # (waits for the pending call)
+        assert np.array_equal(c, c0, equal_nan=True) and np.array_equal(K, K0, equal_nan=True) and np.array_equal(H, H0, equal_nan=True)
+        t = h.timings()
+        assert t["knn_ms"] > 0 and t["total_ms"] > 0 and t["redone_queries"] == 0 and t["algo"] == t_ref["algo"]
+        i0, d0, _ = ref.get_neighbors(0, 1000)
+        i1, d1, _ = h.get_neighbors(0, 1000)
+        assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    # an error inside an asynchronous call: reported at once, the pending call is finished, the handle goes on
+    h.set_points(even)
+    h.curvature(50)
+    with pytest.raises(ValueError):
+        h.curvature(600)
+    h.curvature(50)
+    _, K, _, _ = h.get_fit(0, 100, coefs=False, H2=False)
+    ref.set_points(even)
+    ref.curvature(50)
+    _, K0, _, _ = ref.get_fit(0, 100, coefs=False, H2=False)
+    assert np.array_equal(K, K0)
+    # synchronous where the verdict of the sweep is needed before returning
+    h.set_query_range(1000, 50_000)
+    h.curvature(50)
+    assert h.stage_times_done().knn_ms == h.timings()["knn_ms"] > 0
+    h.set_query_range(0, len(even))
+    h.set_stats(True)
+    h.curvature(50)
+    assert h.timings()["redone_queries"] > 0
+    h.set_stats(False)
+    h.set_async(False)
+    h.curvature(50)
+    assert h.timings()["fit_ms"] > 0
+    h.close()
+    ref.close()
+
+
 def test_random_cross_check_of_slab_ownership(gpu):
     """Fixed-seed slice of tools/fuzz_slab.py: the random clouds of fuzz_gpu (ties, blobs of uneven density, outliers, far
     offsets, anisotropic boxes; float32, >= 4096 points), random k, eps and number of slabs -- every slab on one handle,

@@ -57,10 +57,10 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
         h.close()
         return it, f"seed={seed0} step {it}: {msg}; last ops: {log[-8:]}"
     while time.time() < t_end and (cases is None or it < cases):
-        ops = ["cloud"] if pts is None else ["cloud", "range", "knn", "knn", "curv", "curv", "stats", "factor", "query", "voxel", "survar"]
+        ops = ["cloud"] if pts is None else ["cloud", "range", "knn", "knn", "curv", "curv", "stats", "factor", "query", "voxel", "survar", "async"]
         if knn: ops += ["fit", "get_nbr", "get_rows", "rows_fit", "rows_fit64", "study"]
         if fit: ops += ["get_fit", "get_fit"]
-        w = np.array([0.25 if o in ("cloud", "range") else 0.5 if o in ("stats", "factor", "voxel") else 1.0 for o in ops]) if pts is not None else None
+        w = np.array([0.25 if o in ("cloud", "range") else 0.5 if o in ("stats", "factor", "voxel", "async") else 1.0 for o in ops]) if pts is not None else None
         op = str(rng.choice(ops, p=None if w is None else w / w.sum())); it += 1
         log.append(op)
         if verbose: print(it, op, knn, fit[0] if fit else None, flush=True)
@@ -79,6 +79,7 @@ def run(seed0=0, budget=None, cases=None, verbose=False):
         elif op == "fit":
             h.fit(); fit = ("cloud",) + knn
         elif op == "stats": h.set_stats(bool(rng.integers(0, 2)))
+        elif op == "async": h.set_async(bool(rng.integers(0, 2)))       # fused calls return early; everything else waits for them
         elif op == "factor": h.set_grid_param(float(rng.choice([0.0, 0.0, 0.35, 0.5, 0.8])))
         elif op == "get_nbr":
             k, eps, klo, khi = knn
