@@ -92,7 +92,7 @@ static void finish_pending(pct_ctx* ctx, const hipEvent_t* ev) {
     t.grid_ms = ev_ms(ev, 2, 3);
     t.knn_ms = ev_ms(ev, 3, 4);
     t.knn_fast_ms = ctx->pend_sorted ? ev_ms(ev, 3, 7) : 0.f;
-    t.fit_ms = ev_ms(ev, 5, 6);
+    t.fit_ms = ev_ms(ev, 4, 6);
     t.total_ms = ev_ms(ev, 2, 6);
     t.fit_svd_rows = *svd_slot(ctx, ctx->pend_par);
     const int64_t redone = (int64_t)(unsigned)(c[7] & 0xFFFFFFFFull);
@@ -664,7 +664,8 @@ static int curvature_async(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     int st = run_knn(ctx, k, eps, algo, true);
     if (st == PCT_OK) {
         st = [&]() -> int {
-            PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+            // (no event of its own for the start of the fit: it starts where the sweep's last event, ev[4], was recorded --
+            // every event record is a marker packet between two kernels, ~3 us of dispatch gap)
             ctx->stats_mirrored = false;
             ctx->stats_mirror_req = true;
             const int fs = pct_launch_fit_table(ctx);
@@ -715,7 +716,6 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
     for (int attempt = 0; attempt < 2; ++attempt) {
         bool again = false;
         PCT_TRY(run_knn(ctx, k, eps, algo, true));
-        PCT_HIP(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
         ctx->stats_mirrored = false;
         ctx->stats_mirror_req = true;
         PCT_TRY(pct_launch_fit_table(ctx));
@@ -727,7 +727,7 @@ int pct_curvature(pct_ctx* ctx, int32_t k, double eps, int32_t algo) {
         ctx->retries = 1;
         ctx->cull_box_valid = false;   // the cached box was too small for this cloud: measure it again next time
     }
-    ctx->tm.fit_ms = ev_ms(ctx, 5, 6);
+    ctx->tm.fit_ms = ev_ms(ctx, 4, 6);            // (the fit starts where the sweep's last event was recorded)
     ctx->tm.fit_svd_rows = *svd_slot(ctx, 0);
     ctx->tm.total_ms = ev_ms(ctx, 2, 6);
     ctx->tm_done = ctx->tm;
