@@ -1804,7 +1804,9 @@ struct DuoLds {
     int offc[16];                                        // sorted position - flat slot, per non-empty run
 };
 
-template <bool EPS, bool DIST>
+// Q64: a float64 cloud, as in k_knn_pair -- float32-rounded candidates, native float64 queries, every bound taken from the
+// float32 pre-selection widened by eq = |q64 - q32|.
+template <bool EPS, bool DIST, bool Q64 = false>
 __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
     constexpr int CAP = kDuoCap, LIST = 128, SLOT_BITS = 7, KEY_BITS = 32 - SLOT_BITS;
     static_assert(CAP % 128 == 0 && CAP <= 1024, "slot ids: 10 bits of slot, 4 bits of run index");
@@ -1839,7 +1841,20 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
         }
     }
     float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (lane < nq) my_q = a.pts[qs + lane];
+    double my_qx = 0., my_qy = 0., my_qz = 0.;
+    float my_eq = 0.f;       // Q64: distance between the float64 query and its float32 rounding, rounded up
+    if (lane < nq) {
+        my_q = a.pts[qs + lane];
+        if constexpr (Q64) {
+            const double4 qd = a.ptsd[qs + lane];
+            my_qx = qd.x; my_qy = qd.y; my_qz = qd.z;
+        }
+    }
+    if constexpr (Q64) {
+        const double ex = my_qx - (double)my_q.x, ey = my_qy - (double)my_q.y, ez = my_qz - (double)my_q.z;
+        my_eq = (float)sqrt((ex * ex + ey * ey) + ez * ez) * (1.0f + 0x1p-22f);
+        if (!(my_eq >= 0.f)) my_eq = INFINITY;
+    }
     int my_pre = 0, m = 0;
     {
         int acc = 0;
@@ -1914,15 +1929,17 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
     constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
     unsigned my_gkey;
     {
-        const double gx = ((double)my_q.x - a.g.ox) * a.g.inv_cell - cx;
-        const double gy = ((double)my_q.y - a.g.oy) * a.g.inv_cell - cy;
-        const double gz = ((double)my_q.z - a.g.oz) * a.g.inv_cell - cz;
+        const double lqx = Q64 ? my_qx : (double)my_q.x, lqy = Q64 ? my_qy : (double)my_q.y, lqz = Q64 ? my_qz : (double)my_q.z;
+        const double gx = (lqx - a.g.ox) * a.g.inv_cell - cx;
+        const double gy = (lqy - a.g.oy) * a.g.inv_cell - cy;
+        const double gz = (lqz - a.g.oz) * a.g.inv_cell - cz;
         const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
         my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
     const float cell2f = (float)(edge * edge);
     const float eps2a = EPS ? (float)fmin(eps2 * (1.0 + 0x1p-18), 3.0e38) : INFINITY;
+    const double eps1 = EPS ? sqrt(eps2) * (1.0 + 0x1p-50) : 0.0;       // eps itself, rounded up (Q64)
     float t_prev_f = 0.f;
     unsigned long long redo_mask = 0ull;
 
@@ -1943,7 +1960,12 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
             const float ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.x), qi));
             const float ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.y), qi));
             const float az = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_q.z), qi));
-            const double qx = (double)ax, qy = (double)ay, qz = (double)az;
+            // the query the exact keys measure from: the float32 record widened, or (Q64) the native coordinates
+            const auto rl64 = [&](double v, int l) {
+                return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+            };
+            const double qx = Q64 ? rl64(my_qx, qi) : (double)ax, qy = Q64 ? rl64(my_qy, qi) : (double)ay, qz = Q64 ? rl64(my_qz, qi) : (double)az;
+            const float eq = Q64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_eq), qi)) : 0.f;
             // ---- float32 squared distances of all staged candidates (packed: two batches per instruction) ----------
             float ap[NBU];
 #pragma unroll
@@ -1958,7 +1980,12 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
                 ap[2 * p2 + 1] = d.y;
             }
             // ---- threshold: k+1 <= #(d < T) <= LIST, never beyond the eps ball (wave-uniform search) -----------------
-            const float T_init = eps2a;
+            // +inf without eps; Q64: exact d < eps  =>  d' < eps + eq
+            float T_init = eps2a;
+            if constexpr (EPS && Q64) {
+                const double ee = eps1 + (double)eq;
+                T_init = (float)fmin(ee * ee * (1.0 + 0x1p-18), 3.0e38);
+            }
             int tot = m;
             if constexpr (EPS) {
                 tot = 0;
@@ -1992,7 +2019,13 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
                 if (!found || __builtin_amdgcn_ballot_w64(!(T >= 1e-30f)) != 0ull) { redo_mask |= 1ull << qi; continue; }
                 t_prev_f = T;
                 // smallest exact key a candidate cut by the float32 threshold can have (k_knn_pair)
-                bkey = (unsigned)fmin((double)T * (1.0 - 0x1p-20) * scale, 4294967294.0);
+                double lo2 = (double)T * (1.0 - 0x1p-20);
+                if constexpr (Q64) {
+                    // (sqrt(L) - eq)^2 >= L - 2 eq sqrt(L); an upper bound of the root is enough: float32 root, rounded up
+                    const double root_up = (double)__builtin_sqrtf(T) * (1.0 + 0x1p-21);
+                    lo2 = fmax(lo2 - 2.0 * (double)eq * root_up, 0.0);
+                }
+                bkey = (unsigned)fmin(lo2 * scale, 4294967294.0);
             }
             // ---- compact the staged slots of the survivors, two batches per block of instructions (k_knn_pair's
             // hand-placed sequence; here both batches append to the same list)
@@ -2335,8 +2368,8 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
     const bool pair_kernel = !exact_only && phase == 0 && q64_ok_ && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
                              k + 1 <= pct_fast_r1_max() && ctx->n_items < ((int64_t)1 << 31) - 8 && !pct_getenv("PCT_NO_PAIR") &&
                              !pct_getenv("PCT_NO_PAIR_KERNEL");
-    // rows of 65 .. 128 entries of a float32 cloud: the same scheme with two list registers (k_knn_duo)
-    const bool duo_kernel = !exact_only && phase == 0 && !ctx->has_f64 && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
+    // rows of 62 .. 128 entries: the same scheme with two list registers (k_knn_duo)
+    const bool duo_kernel = !exact_only && phase == 0 && q64_ok_ && f32_ok_ && !ctx->own_flag && !ctx->level_mode && ctx->n_items > 0 &&
                             k + 1 > pct_fast_r1_max() && k + 1 <= 128 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
                             !pct_getenv("PCT_NO_PAIR") && !pct_getenv("PCT_NO_DUO_KERNEL");
     const bool skip_dist = (pair_kernel || duo_kernel) && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
@@ -2398,6 +2431,12 @@ int pct_launch_knn_grid(pct_ctx* ctx, int32_t k, double eps, bool exact_only, in
             const dim3 gridp((unsigned)((n_blk + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
             if (duo_kernel) {
                 const dim3 gridd((unsigned)n_blk), blockd(64);
+                if (ctx->has_f64) {
+                    if (e && skip_dist) PCT_LAUNCH((k_knn_duo<true, false, true>), gridd, blockd, 0, ctx->stream, pa);
+                    else if (e) PCT_LAUNCH((k_knn_duo<true, true, true>), gridd, blockd, 0, ctx->stream, pa);
+                    else if (skip_dist) PCT_LAUNCH((k_knn_duo<false, false, true>), gridd, blockd, 0, ctx->stream, pa);
+                    else PCT_LAUNCH((k_knn_duo<false, true, true>), gridd, blockd, 0, ctx->stream, pa);
+                } else
                 if (e && skip_dist) PCT_LAUNCH((k_knn_duo<true, false>), gridd, blockd, 0, ctx->stream, pa);
                 else if (e) PCT_LAUNCH((k_knn_duo<true, true>), gridd, blockd, 0, ctx->stream, pa);
                 else if (skip_dist) PCT_LAUNCH((k_knn_duo<false, false>), gridd, blockd, 0, ctx->stream, pa);
