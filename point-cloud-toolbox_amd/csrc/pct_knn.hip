@@ -1794,7 +1794,10 @@ __device__ __forceinline__ void sort_duo_asm(unsigned& ea, unsigned& eb, const S
 // Staging capacity: cells are sized for 0.35 (k + 1) points, a surface's 27-cell stencil then holds 12 - 14 cells' worth --
 // 400 - 470 candidates at k = 64 .. 80: 512 slots sent 8 % of the items (k = 64) to 30 % (k = 80) to the exact sweep,
 // 768 slots (4 waves per SIMD with the 16-bit survivor list) send a handful.
-constexpr int kDuoCap = 768;
+#ifndef PCT_DUO_CAP
+#define PCT_DUO_CAP 768
+#endif
+constexpr int kDuoCap = PCT_DUO_CAP;
 template <bool DIST>
 struct DuoLds {
     float cx[kDuoCap], cy[kDuoCap], cz[kDuoCap];         // staged stencil, 12 B per candidate
@@ -1807,7 +1810,7 @@ struct DuoLds {
 // Q64: a float64 cloud, as in k_knn_pair -- float32-rounded candidates, native float64 queries, every bound taken from the
 // float32 pre-selection widened by eq = |q64 - q32|.
 template <bool EPS, bool DIST, bool Q64 = false>
-__global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
+__global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(PairArgs a) {
     constexpr int CAP = kDuoCap, LIST = 128, SLOT_BITS = 7, KEY_BITS = 32 - SLOT_BITS;
     static_assert(CAP % 128 == 0 && CAP <= 1024, "slot ids: 10 bits of slot, 4 bits of run index");
     __shared__ DuoLds<DIST> L;
@@ -2142,7 +2145,9 @@ __global__ __launch_bounds__(64, 4) void k_knn_duo(PairArgs a) {
         else if (nbp == 3) query_loop(integral_constant<int, 3>{});
         else if (nbp == 4) query_loop(integral_constant<int, 4>{});
         else if (nbp == 5) query_loop(integral_constant<int, 5>{});
-        else query_loop(integral_constant<int, 6>{});
+        else if (nbp == 6) query_loop(integral_constant<int, 6>{});
+        else if (nbp == 7) query_loop(integral_constant<int, (CAP >= 896 ? 7 : 1)>{});
+        else query_loop(integral_constant<int, (CAP >= 1024 ? 8 : 1)>{});
     }
     if (redo_mask) {
         const int cnt = (int)__popcll(redo_mask);
