@@ -514,6 +514,34 @@ __global__ __launch_bounds__(kBlock) void k_hist(const float4* __restrict__ pts4
     }
 }
 
+// k_pack folded in (a handle fed a stream of similar clouds builds on the previous cloud's box without waiting for the new
+// one: no float4 copy of the cloud is needed before the histogram): reads the caller's xyz rows, bins them, and leaves the
+// bounding box / moments / finite check of the cloud as per-block records for k_pack_final.  Whole-cloud handles only
+// (every point owned or not by its index; no level pass, no sub-box).
+__global__ __launch_bounds__(kBlock) void k_hist_raw(const float* __restrict__ xyz, int64_t n, pct_grid g, int q_begin, int q_end,
+                                                     int* __restrict__ cell_of, int* __restrict__ rank_of,
+                                                     int* __restrict__ cell_own, int* __restrict__ cell_oth, PackRed* __restrict__ parts) {
+    const float sh[3] = {0.f, 0.f, 0.f};
+    PackAcc acc;
+    acc.init();
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const float x = xyz[3 * i + 0], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        const bool ok = isfinite(x) && isfinite(y) && isfinite(z);
+        acc.bad |= !ok;
+        if (ok) acc.add(x, y, z, sh);
+        // (a non-finite row makes the call fail at its next read-back; it is binned at the origin meanwhile)
+        const int cx = cell_coord(ok ? (double)x : g.ox, g.ox, g.inv_cell, g.nx);
+        const int cy = cell_coord(ok ? (double)y : g.oy, g.oy, g.inv_cell, g.ny);
+        const int cz = cell_coord(ok ? (double)z : g.oz, g.oz, g.inv_cell, g.nz);
+        const int c = (cz * g.ny + cy) * g.nx + cx;
+        cell_of[i] = c;
+        if (i >= q_begin && i < q_end) rank_of[i] = atomicAdd(&cell_own[c], 1);
+        else rank_of[i] = atomicAdd(&cell_oth[c], 1) | (int)0x80000000;
+    }
+    if (parts) acc.commit(parts + blockIdx.x);
+}
+
 // The same for the later passes of the density-adaptive sweep (pct_levels.hip), whose cells are sized for ONE band of
 // densities while every point is still a candidate: the denser part of the cloud then piles into a handful of cells
 // and its atomics serialise at the memory side (~88 per microsecond and address: a 1/r^2 scan spent 1-2 ms per pass
@@ -717,6 +745,30 @@ __global__ __launch_bounds__(kBlock) void k_scatter(const float4* __restrict__ p
     const float4 p = pts4[i];
     sorted4[pos] = p;
     if (pts4d) sorted4d[pos] = pts4d[__float_as_int(p.w)];      // float64 records stay in public order (never culled)
+}
+
+// ... from the caller's xyz rows (k_hist_raw's counterpart)
+__global__ __launch_bounds__(kBlock) void k_scatter_raw(const float* __restrict__ xyz, const int* __restrict__ cell_of,
+                                                        const int* __restrict__ cell_start, const int* __restrict__ cell_own,
+                                                        const int* __restrict__ own_start, const int* __restrict__ rank_of,
+                                                        int64_t n, int g_begin, float4* __restrict__ sorted4,
+                                                        int* __restrict__ row_of, int* __restrict__ owned_pos,
+                                                        const double4* __restrict__ pts4d, double4* __restrict__ sorted4d) {
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const int c = cell_of[i];
+    const int r = rank_of[i];
+    int pos;
+    if (r >= 0) {
+        pos = cell_start[c] + r;
+        const int row = own_start[c] + r;
+        owned_pos[row] = pos;
+        row_of[i - g_begin] = row;
+    } else {
+        pos = cell_start[c] + cell_own[c] + (r & 0x7fffffff);
+    }
+    sorted4[pos] = make_float4(xyz[3 * i + 0], xyz[3 * i + 1], xyz[3 * i + 2], __int_as_float((int)i));
+    if (pts4d) sorted4d[pos] = pts4d[i];
 }
 
 __global__ __launch_bounds__(256) void k_gather_int(const int* __restrict__ map, int* __restrict__ io, int64_t n) {
@@ -1057,12 +1109,18 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         }
         PCT_TRY(trim_box(ctx, red, bbox));
     } else if (spec) {
-        PCT_TRY(pack_all(ctx, bbox, &red, true));
+        // no pack pass at all: the histogram reads the caller's rows and takes the cloud's box along (k_hist_raw)
+        PCT_TRY(red_reset(ctx, grid_1d(ctx->n, kBlock, 0), false));
+        ctx->pts4_valid = false;
+        ctx->n_grid = ctx->n;
+        ctx->g_begin = ctx->q_begin;
+        ctx->culled = false;
         for (int a = 0; a < 6; ++a) bbox[a] = ctx->spec_bbox[a];
     } else {
         PCT_TRY(pack_all(ctx, bbox, &red));
         PCT_TRY(trim_box(ctx, red, bbox));
     }
+    const bool raw = spec;                                                // (spec is cleared once the box has been checked)
     const bool sub_box = ctx->level_edge > 0 && ctx->level_box_valid;
     const int64_t n = ctx->n_grid;                                        // points the grid holds
     const int g_begin = own_flag ? 0 : (int)ctx->g_begin, g_end = own_flag ? 0 : (int)(ctx->g_begin + n_owned);
@@ -1158,6 +1216,12 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
             PCT_HIP(ctx, hipMemsetAsync(ctx->cell_oth.p, 0, (size_t)g.ncell * sizeof(int), ctx->stream));
         }
         const float4* src = from_base ? (const float4*)ctx->lvl_src.p : (const float4*)ctx->pts4.p;
+        if (raw) {
+            const int nhb = grid_1d(n, kBlock, 0);
+            PCT_LAUNCH(k_hist_raw, dim3(nhb), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, n, g, g_begin, g_end, (int*)ctx->cell_of.p,
+                       (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p, sharded ? (int*)ctx->cell_oth.p : nullptr, spec ? red_parts(ctx) : nullptr);
+            if (spec) PCT_TRY(red_fold(ctx, nhb, false));
+        } else
         if (from_base)
             PCT_LAUNCH(k_hist_agg, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream, src, n, g, own_flag, ctx->own_lo,
                                ctx->own_hi, sub_box ? 1 : 0, (int*)ctx->cell_of.p, (int*)ctx->cell_fill.p, (int*)ctx->cell_own.p,
@@ -1190,6 +1254,12 @@ int pct_build_grid(pct_ctx* ctx, int32_t k, double eps) {
         PCT_LAUNCH(k_scan_apply, dim3(nblk), dim3(kBlock), 0, ctx->stream,
                            (const int*)ctx->cell_own.p, sharded ? (const int*)ctx->cell_oth.p : nullptr, g.ncell, items_q,
                            (const int4*)ctx->scan_tmp.p, (int*)ctx->cell_cnt.p, (int*)ctx->own_start.p, (int2*)ctx->occ.p);
+        if (raw)
+            PCT_LAUNCH(k_scatter_raw, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream, ctx->xyz_view, (const int*)ctx->cell_of.p,
+                       (const int*)ctx->cell_cnt.p, (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
+                       g_begin, (float4*)ctx->sorted4.p, (int*)ctx->row_of.p, (int*)ctx->owned_pos.p,
+                       ctx->has_f64 ? (const double4*)ctx->pts4d.p : nullptr, ctx->has_f64 ? (double4*)ctx->sorted4d.p : nullptr);
+        else
         PCT_LAUNCH(k_scatter, dim3(grid_1d(n, kBlock, 0)), dim3(kBlock), 0, ctx->stream,
                            src, (const int*)ctx->cell_of.p, (const int*)ctx->cell_cnt.p,
                            (const int*)ctx->cell_own.p, (const int*)ctx->own_start.p, (const int*)ctx->cell_fill.p, n,
