@@ -440,6 +440,35 @@ def main():
             e2e = (time.perf_counter() - t0) / m
             extras["end_to_end"] = {"value": n_total / e2e, "unit": "points/s", "ms_per_step": 1e3 * e2e,
                                     "what": "H2D of float32 coordinates (12 B/point, pageable host memory) + step + D2H of K, H (8 B/point, one copy)"}
+            # ... and for a STREAM of clouds from host memory: two handles of this GPU in turn, asynchronous calls -- the
+            # transfers of one cloud (pageable host memory both ways) run while the device works on the other
+            try:
+                hb = _capi.Handle(local_rank)
+                hb.set_async(True)
+                pair = (handle, hb)
+                stream_last = []
+                t0 = 0.0
+                for it in range(2 * m + 2):
+                    hh = pair[it & 1]
+                    if it >= 2:
+                        got = hh.get_fit(0, n_total, coefs=False, H2=False)   # results of the cloud this handle took two turns ago
+                        if it >= 2 * m:                                   # (kept for the check after the clock has stopped)
+                            stream_last.append((got[1].copy(), got[2].copy()) if it == 2 * m else (got[1], got[2]))
+                    if it == 2:
+                        t0 = time.perf_counter()
+                    if it < 2 * m + 2 - 2:
+                        hh.set_points(local)
+                        hh.curvature(k, eps, _capi.KNN_GRID)
+                e2p = (time.perf_counter() - t0) / (2 * m - 2)
+                hb.close()
+                if len(stream_last) == 2 and not (np.array_equal(stream_last[0][0], stream_last[1][0], equal_nan=True)
+                                                  and np.array_equal(stream_last[0][1], stream_last[1][1], equal_nan=True)):
+                    raise RuntimeError("the two handles of the stream disagree")      # (the same cloud went to both: same bits)
+                extras["end_to_end_stream"] = {"value": n_total / e2p, "unit": "points/s", "ms_per_cloud": 1e3 * e2p,
+                                               "what": "the same transfers and step for a stream of clouds: two handles in turn, "
+                                                       "pct_set_async -- one cloud's H2D / D2H overlap the other's kernels"}
+            except Exception as ex:                                       # (an extra: never fails the line)
+                extras["end_to_end_stream"] = {"error": repr(ex)}
             # the sweep in the mode SURVEY 8(d) prices: plant_kdtree's, which writes indices AND distances (12 + 8k B/point)
             acc8 = 0.0
             for _ in range(10):
