@@ -229,6 +229,7 @@ def release_handle(h):
         return
     try:
         h.set_stats(False)
+        h.set_async(False)
         for attr in ("k", "eps"):
             if hasattr(h, attr):
                 delattr(h, attr)

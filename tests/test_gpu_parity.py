@@ -1675,6 +1675,37 @@ def test_asynchronous_calls_of_a_stream_of_clouds(gpu):
     ref.close()
 
 
+def test_curvature_stream_gives_every_cloud_its_own_values_in_order(gpu):
+    """point_cloud_toolbox_amd.stream.curvature_stream: clouds of different sizes and dtypes through two handles in turn
+    (asynchronous calls, transfers under the other cloud's kernels) -- the values of a plain handle, in input order; a
+    generator as input; one cloud; none."""
+    capi, shapes = gpu["capi"], gpu["shapes"]
+    from point_cloud_toolbox_amd.stream import curvature_stream
+    clouds = [shapes.torus_random(30_000, seed=1), shapes.egg_carton_random(45_000, seed=2), shapes.torus_random(8_000, seed=3).astype(np.float64),
+              shapes.fibonacci_sphere(20_000), shapes.torus_random(30_000, seed=5), shapes.egg_carton_random(5_000, seed=6), shapes.torus_random(61_000, seed=7)]
+    ref = capi.Handle(0)
+    want = []
+    for c in clouds:
+        ref.set_points(c)
+        ref.curvature(40)
+        _, K, H, _ = ref.get_fit(0, len(c), coefs=False, H2=False)
+        want.append((K, H))
+    got = list(curvature_stream((c for c in clouds), 40))
+    assert len(got) == len(want)
+    for (K, H), (K0, H0) in zip(got, want):
+        assert np.array_equal(K, K0, equal_nan=True) and np.array_equal(H, H0, equal_nan=True)
+    assert len(list(curvature_stream(clouds[:1], 40))) == 1 and list(curvature_stream([], 40)) == []
+    with pytest.raises(ValueError):
+        list(curvature_stream([clouds[0], np.zeros((10, 2))], 40))
+    # the handles went back to the pool in the plain state: the class works as before
+    pc = gpu["PointCloud"](points=clouds[0], normals=np.zeros((len(clouds[0]), 0)))
+    pc.plant_kdtree(40)
+    K, H = pc.compute_pointwise_explicit_quadratic_curvature()
+    assert np.array_equal(np.asarray(K, np.float32), want[0][0], equal_nan=True)
+    pc.close()
+    ref.close()
+
+
 def test_random_cross_check_of_slab_ownership(gpu):
     """Fixed-seed slice of tools/fuzz_slab.py: the random clouds of fuzz_gpu (ties, blobs of uneven density, outliers, far
     offsets, anisotropic boxes; float32, >= 4096 points), random k, eps and number of slabs -- every slab on one handle,
