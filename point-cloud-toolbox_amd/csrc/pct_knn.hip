@@ -1798,9 +1798,9 @@ __device__ __forceinline__ void sort_duo_asm(unsigned& ea, unsigned& eb, const S
 #define PCT_DUO_CAP 768
 #endif
 constexpr int kDuoCap = PCT_DUO_CAP;
-template <bool DIST>
+template <bool DIST, int CAP>
 struct DuoLds {
-    float cx[kDuoCap], cy[kDuoCap], cz[kDuoCap];         // staged stencil, 12 B per candidate
+    float cx[CAP], cy[CAP], cz[CAP];                     // staged stencil, 12 B per candidate
     unsigned short pend[128 + 8];                        // staged slot (| run << 10) of survivor s; (first: the run-start bit string)
     int pay_p[128];                                      // sorted position of survivor s
     float pay_d[DIST ? 128 : 1];                         // its float32 distance
@@ -1809,11 +1809,13 @@ struct DuoLds {
 
 // Q64: a float64 cloud, as in k_knn_pair -- float32-rounded candidates, native float64 queries, every bound taken from the
 // float32 pre-selection widened by eq = |q64 - q32|.
-template <bool EPS, bool DIST, bool Q64 = false>
-__global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(PairArgs a) {
-    constexpr int CAP = kDuoCap, LIST = 128, SLOT_BITS = 7, KEY_BITS = 32 - SLOT_BITS;
+// TREE: the items of the hierarchical cell list (as in k_knn_pair), 1024 staged slots -- what pct_tree.hip refines
+// segments for when two list registers are in use.
+template <bool EPS, bool DIST, bool Q64 = false, bool TREE = false>
+__global__ __launch_bounds__(64, ((TREE ? PCT_TREE_CAP2 : PCT_DUO_CAP) <= 768 ? 4 : 3)) void k_knn_duo(PairArgs a) {
+    constexpr int CAP = TREE ? PCT_TREE_CAP2 : kDuoCap, LIST = 128, SLOT_BITS = 7, KEY_BITS = 32 - SLOT_BITS;
     static_assert(CAP % 128 == 0 && CAP <= 1024, "slot ids: 10 bits of slot, 4 bits of run index");
-    __shared__ DuoLds<DIST> L;
+    __shared__ DuoLds<DIST, CAP> L;
     const int lane = lane_id();
     const int item = a.items_per_xcd ? ((int)blockIdx.x & 7) * a.items_per_xcd + ((int)blockIdx.x >> 3) : (int)blockIdx.x;
     if (item >= a.n_items) return;
@@ -1822,27 +1824,53 @@ __global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(Pa
 
     // ---- the work item, its stencil and its queries: as in k_knn_pair -----------------------------------------------
     const int2 it2 = a.items[item];
-    const int cell = __builtin_amdgcn_readfirstlane(it2.x);
-    const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
-    const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
-    const int cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
-    const int rem = cell - cz * (nx * ny);
-    const int cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
-    const int cx = rem - cy * nx;
-    const int c0 = cs[cell];
-    const int qs = c0 + chunk * a.items_q;
-    const int nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
-    const int row0 = a.own_start[cell] + chunk * a.items_q;
-
+    constexpr int NRUNS = TREE ? 27 : 9;
+    int cx, cy, cz, qs, nq, row0;
     int run_s = 0, run_len = 0;
-    if (lane < 9) {
-        const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
-        if (z >= 0 && z < nz && y >= 0 && y < ny) {
-            const int row = (z * ny + y) * nx;
-            run_s = cs[row + max(cx - 1, 0)];
-            run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+    pct_grid g_lvl;                                               // TREE: the grid of the item's level
+    if constexpr (TREE) {
+        const int seg = __builtin_amdgcn_readfirstlane(it2.y);
+        if (seg < 0) return;                                      // an item of a segment that was split (k_tree_refine)
+        const unsigned packed = (unsigned)__builtin_amdgcn_readfirstlane(it2.x);
+        qs = (int)(packed & 0x3ffffffu);
+        nq = (int)(packed >> 26) + 1;
+        row0 = qs;
+        const int4 hd = a.tree_seg[seg];
+        const int level = __builtin_amdgcn_readfirstlane(hd.x);
+        cx = __builtin_amdgcn_readfirstlane(hd.y);
+        cy = __builtin_amdgcn_readfirstlane(hd.z);
+        cz = __builtin_amdgcn_readfirstlane(hd.w);
+        g_lvl = a.g;
+        g_lvl.cell = __builtin_ldexp(a.g.cell, level);
+        g_lvl.inv_cell = __builtin_ldexp(a.g.inv_cell, -level);
+        g_lvl.nx = g_lvl.ny = g_lvl.nz = 1 << (a.tree_bits - level);
+        if (lane < 27) {
+            const int2 r = a.tree_runs[(int64_t)seg * 27 + lane];
+            run_s = r.x;
+            run_len = r.y;
+        }
+    } else {
+        const int cell = __builtin_amdgcn_readfirstlane(it2.x);
+        const int chunk = __builtin_amdgcn_readfirstlane(it2.y);
+        const int nx = a.g.nx, ny = a.g.ny, nz = a.g.nz;
+        cz = (int)(((unsigned long long)(unsigned)cell * a.magic_xy) >> a.shift_xy);
+        const int rem = cell - cz * (nx * ny);
+        cy = (int)(((unsigned long long)(unsigned)rem * a.magic_x) >> a.shift_x);
+        cx = rem - cy * nx;
+        const int c0 = cs[cell];
+        qs = c0 + chunk * a.items_q;
+        nq = min(c0 + a.cell_own[cell], qs + a.items_q) - qs;
+        row0 = a.own_start[cell] + chunk * a.items_q;
+        if (lane < 9) {
+            const int z = cz + kRowOrder[lane][0], y = cy + kRowOrder[lane][1];
+            if (z >= 0 && z < nz && y >= 0 && y < ny) {
+                const int row = (z * ny + y) * nx;
+                run_s = cs[row + max(cx - 1, 0)];
+                run_len = cs[row + min(cx + 1, nx - 1) + 1] - run_s;
+            }
         }
     }
+    const pct_grid& G = TREE ? g_lvl : a.g;
     float4 my_q = make_float4(0.f, 0.f, 0.f, 0.f);
     double my_qx = 0., my_qy = 0., my_qz = 0.;
     float my_eq = 0.f;       // Q64: distance between the float64 query and its float32 rounding, rounded up
@@ -1862,13 +1890,14 @@ __global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(Pa
     {
         int acc = 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int t = 0; t < NRUNS; ++t) {
             my_pre = lane == t ? acc : my_pre;
             acc += __builtin_amdgcn_readlane(run_len, t);
         }
         m = acc;
     }
-    if (m > CAP) {
+    const bool crowded = TREE && __popcll(__builtin_amdgcn_ballot_w64(lane < NRUNS && run_len > 0)) > 16;      // (four bits of run index)
+    if (m > CAP || crowded) {
         int base = 0;
         if (lane == 0) base = atomicAdd(a.redo_count, nq);
         base = __builtin_amdgcn_readfirstlane(base);
@@ -1885,7 +1914,7 @@ __global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(Pa
         static_assert(sizeof(L.pend) >= CAP / 8, "the run-start bit string lives in the survivor list");
         if (lane < CAP / 32) bits[lane] = 0u;
         wave_lds_sync();
-        const bool nonempty = lane < 9 && run_len > 0;
+        const bool nonempty = lane < NRUNS && run_len > 0;
         const unsigned long long ne = __builtin_amdgcn_ballot_w64(nonempty);
         if (nonempty) {
             atomicOr(&bits[my_pre >> 5], 1u << (my_pre & 31));
@@ -1927,16 +1956,16 @@ __global__ __launch_bounds__(64, (PCT_DUO_CAP <= 768 ? 4 : 3)) void k_knn_duo(Pa
     const int k = a.k;
     const double eps2 = EPS ? a.eps2 : (double)INFINITY;
     constexpr double kKeyRange = 2.3;
-    const double edge = a.g.cell;
+    const double edge = G.cell;
     const double scale = (double)(1u << KEY_BITS) / (kKeyRange * edge * edge);
     constexpr unsigned key_max = (1u << KEY_BITS) - 1u;
     unsigned my_gkey;
     {
         const double lqx = Q64 ? my_qx : (double)my_q.x, lqy = Q64 ? my_qy : (double)my_q.y, lqz = Q64 ? my_qz : (double)my_q.z;
-        const double gx = (lqx - a.g.ox) * a.g.inv_cell - cx;
-        const double gy = (lqy - a.g.oy) * a.g.inv_cell - cy;
-        const double gz = (lqz - a.g.oz) * a.g.inv_cell - cz;
-        const double g2 = fmin(guaranteed_r2(a.g, cx, cy, cz, gx, gy, gz, 1), limit_r2(a.g, cx, cy, cz, gx, gy, gz));
+        const double gx = (lqx - G.ox) * G.inv_cell - cx;
+        const double gy = (lqy - G.oy) * G.inv_cell - cy;
+        const double gz = (lqz - G.oz) * G.inv_cell - cz;
+        const double g2 = fmin(guaranteed_r2(G, cx, cy, cz, gx, gy, gz, 1), limit_r2(G, cx, cy, cz, gx, gy, gz));
         my_gkey = g2 == INFINITY ? 0xFFFFFFFFu : (unsigned)fmin(g2 * scale, 4294967294.0);
     }
     const unsigned eps_key = EPS && eps2 < 1e300 ? (unsigned)fmin(ceil(eps2 * scale), 4294967295.0) : 0xFFFFFFFFu;
@@ -2508,9 +2537,11 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
     const int64_t n_rows = ctx->n;
     // one list register: the scalar-lean kernel's TREE instantiation (k_knn_pair); it can leave the distance table out
     // for the fused call, like the uniform list's
-    const bool pair_tree = k + 1 <= pct_fast_r1_max() && ctx->n_items > 0 && ctx->n_items < ((int64_t)1 << 31) - 8 &&
-                           !pct_getenv("PCT_NO_PAIR") && !pct_getenv("PCT_NO_PAIR_KERNEL") && !pct_getenv("PCT_TREE_EXACT_ONLY");
-    const bool skip_dist = pair_tree && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
+    const bool lean_ok = ctx->n_items > 0 && ctx->n_items < ((int64_t)1 << 31) - 8 && !pct_getenv("PCT_NO_PAIR") &&
+                         !pct_getenv("PCT_TREE_EXACT_ONLY");
+    const bool pair_tree = lean_ok && k + 1 <= pct_fast_r1_max() && !pct_getenv("PCT_NO_PAIR_KERNEL");
+    const bool duo_tree = lean_ok && k + 1 > pct_fast_r1_max() && k + 1 <= 128 && !pct_getenv("PCT_NO_DUO_KERNEL");     // two list registers: k_knn_duo
+    const bool skip_dist = (pair_tree || duo_tree) && ctx->skip_dist_req && !pct_getenv("PCT_KEEP_DIST");
     PCT_TRY(reserve_table(ctx, k, eps, !skip_dist));
     PCT_TRY(pct_reserve(ctx, &ctx->redo, ((size_t)n_rows + 16) * sizeof(int)));
     KnnArgs a = make_args(ctx, k, eps, true);
@@ -2534,7 +2565,7 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
         // (Q64); where that distance is not small against the item's cells the proofs fail and the exact sweep answers
 #define PCT_TREE(R_, E_, Q_, GRID_, BLOCK_) \
     PCT_LAUNCH((k_knn_fast<R_, E_, true, true, Q_, true>), GRID_, BLOCK_, 0, ctx->stream, a, items, ctx->n_items, ctx->items_q, redo, redo_count)
-        if (pair_tree) {
+        if (pair_tree || duo_tree) {
             PairArgs pa = {};
             pa.pts = a.pts; pa.ptsd = a.ptsd; pa.cell_start = a.cell_start;
             pa.items = items;
@@ -2546,7 +2577,11 @@ int pct_launch_knn_tree(pct_ctx* ctx, int32_t k, double eps) {
             pa.items_per_xcd = pct_getenv("PCT_NO_XCD_MAP") ? 0 : (int)((ctx->n_items + 7) / 8);
             const int64_t n_blk = pa.items_per_xcd ? (int64_t)pa.items_per_xcd * 8 : ctx->n_items;
             const dim3 gridp((unsigned)((n_blk + kPairWaves - 1) / kPairWaves)), blockp(64 * kPairWaves);
-#define PCT_PAIR_TREE(E_, D_, Q_) PCT_LAUNCH((k_knn_pair<E_, D_, Q_, true>), gridp, blockp, 0, ctx->stream, pa)
+#define PCT_PAIR_TREE(E_, D_, Q_)                                                                       \
+    do {                                                                                                \
+        if (duo_tree) PCT_LAUNCH((k_knn_duo<E_, D_, Q_, true>), dim3((unsigned)n_blk), dim3(64), 0, ctx->stream, pa); \
+        else PCT_LAUNCH((k_knn_pair<E_, D_, Q_, true>), gridp, blockp, 0, ctx->stream, pa);           \
+    } while (0)
             if (ctx->has_f64) {
                 if (e && skip_dist) PCT_PAIR_TREE(true, false, true);
                 else if (e) PCT_PAIR_TREE(true, true, true);
